@@ -1,0 +1,76 @@
+"""ctypes binding of libcmtfpls.so (the C ABI declared in include/cmtfpls.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcmtfpls.so")
+
+_P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/cmtfpls.h one to one
+SIGNATURES = {
+    "cmtfpls_abi_version": (c_int, []),
+    "cmtfpls_last_error": (c_char_p, []),
+    "cmtfpls_colstats_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "cmtfpls_colstats_f32": (c_int, [_P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_colstats_f64": (c_int, [_P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_sweep_partials": (c_int, []),
+    "cmtfpls_center_f32": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P]),
+    "cmtfpls_center_f64": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P]),
+    "cmtfpls_mode0_contract_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "cmtfpls_mode0_contract_f32": (c_int, [_P, c_int64, c_int64, _P, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_mode0_contract_f64": (c_int, [_P, c_int64, c_int64, _P, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_colscale_f64": (c_int, [_P, c_int64, _P, c_double, _P]),
+    "cmtfpls_rank1_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cmtfpls_rank1_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_normalize_f64": (c_int, [_P, c_int64, _P, _P]),
+    "cmtfpls_score_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "cmtfpls_score_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "cmtfpls_deflate_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "cmtfpls_deflate_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "cmtfpls_score_deflate_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "cmtfpls_score_deflate_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "cmtfpls_small_workspace_bytes": (c_size_t, []),
+    "cmtfpls_gram_tn_f64": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int64, _P, _P, c_size_t, _P]),
+    "cmtfpls_rowdot_f64": (c_int, [_P, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_scores_mean_f64": (c_int, [_P, c_int, c_int64, _P, _P]),
+    "cmtfpls_y_deflate_f64": (c_int, [_P, c_int, c_int, c_int64, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_sum_f64": (c_int, [_P, c_int64, _P, _P]),
+}
+
+_lib = None
+
+
+class CmtfplsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcmtfpls.so (built by ``__graft_entry__.build()`` / ``csrc/build.sh``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CmtfplsError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "cmtf_pls_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().cmtfpls_last_error()
+        raise CmtfplsError(f"{what or 'cmtfpls call'} failed with status {rc}: {msg.decode() if msg else ''}")

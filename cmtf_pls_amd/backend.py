@@ -1,0 +1,149 @@
+"""HipBackend: the per-GPU kernel set of the NIPALS engine, one method per reference call site.
+
+Every method launches hand-written gfx950 kernels from libcmtfpls.so (include/cmtfpls.h) on the
+current torch stream; torch is used only to own device memory and the stream.  There is no CPU
+path: constructing the backend without a GPU or without the library raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CmtfplsError("cmtf_pls_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.n_partials = int(self.lib.cmtfpls_sweep_partials())
+        self._ws = {}
+        self.rank1_squarings = 24
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = buf
+        return buf
+
+    def empty(self, *shape, dtype=torch.float64) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float64) -> torch.Tensor:
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def _fn(self, base: str, X: torch.Tensor):
+        if X.dtype not in _SUFFIX:
+            raise TypeError(f"X must be float32 or float64 on device, got {X.dtype}")
+        assert X.is_contiguous() and X.device == self.device
+        return getattr(self.lib, f"cmtfpls_{base}_{_SUFFIX[X.dtype]}")
+
+    def _close_partials(self, part: torch.Tensor) -> torch.Tensor:
+        out = self.empty(1)
+        _lib.check(self.lib.cmtfpls_sum_f64(_ptr(part), part.numel(), _ptr(out), self._stream()), "sum")
+        return out
+
+    # -- preprocess: tpls.py:61-71 -----------------------------------------------------------
+    def colstats(self, X2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        I, P = X2.shape
+        ws = self._workspace("contract", self.lib.cmtfpls_colstats_workspace_bytes(I, P))
+        colsum, colcnt = self.empty(P), self.empty(P)
+        _lib.check(self._fn("colstats", X2)(_ptr(X2), I, P, _ptr(colsum), _ptr(colcnt), _ptr(ws), ws.numel(), self._stream()), "colstats")
+        return colsum, colcnt
+
+    def center(self, X2: torch.Tensor, mean: torch.Tensor, want_rowcnt: bool) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+        I, P = X2.shape
+        rowcnt = self.empty(I) if want_rowcnt else None
+        part = self.empty(self.n_partials)
+        _lib.check(self._fn("center", X2)(_ptr(X2), I, P, _ptr(mean), _ptr(rowcnt), _ptr(part), self._stream()), "center")
+        return rowcnt, self._close_partials(part)
+
+    # -- K1: tpls.py:83 / missingvals.py:7-20 ------------------------------------------------
+    def mode0_contract(self, X2: torch.Tensor, u: torch.Tensor, masked: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        I, P = X2.shape
+        ws = self._workspace("contract", self.lib.cmtfpls_mode0_contract_workspace_bytes(I, P))
+        Z = out if out is not None else self.empty(P)
+        _lib.check(self._fn("mode0_contract", X2)(_ptr(X2), I, P, _ptr(u), _ptr(Z), int(masked), _ptr(ws), ws.numel(), self._stream()), "mode0_contract")
+        return Z
+
+    def colscale(self, Z: torch.Tensor, colcnt: torch.Tensor, n_samples: float) -> None:
+        _lib.check(self.lib.cmtfpls_colscale_f64(_ptr(Z), Z.numel(), _ptr(colcnt), float(n_samples), self._stream()), "colscale")
+
+    # -- K2: tpls.py:84-90 -------------------------------------------------------------------
+    def rank1(self, Z: torch.Tensor, A: int, B: int, wA: torch.Tensor, wB: torch.Tensor) -> None:
+        ws = self._workspace("rank1", self.lib.cmtfpls_rank1_workspace_bytes(A, B))
+        _lib.check(self.lib.cmtfpls_rank1_f64(_ptr(Z), A, B, _ptr(wA), _ptr(wB), None, self.rank1_squarings,
+                                              _ptr(ws), ws.numel(), self._stream()), "rank1")
+
+    def normalize(self, v: torch.Tensor) -> None:
+        _lib.check(self.lib.cmtfpls_normalize_f64(_ptr(v), v.numel(), None, self._stream()), "normalize")
+
+    # -- K3: tpls.py:92-99 / missingvals.py:23-38 --------------------------------------------
+    def score(self, X2, A, B, wA, wB, rowcnt, out) -> torch.Tensor:
+        _lib.check(self._fn("score", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), self._stream()), "score")
+        return out
+
+    # -- K6: tpls.py:109 ----------------------------------------------------------------------
+    def deflate(self, X2, A, B, t, wA, wB) -> torch.Tensor:
+        part = self.empty(self.n_partials)
+        _lib.check(self._fn("deflate", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(t), _ptr(wA), _ptr(wB), _ptr(part), self._stream()), "deflate")
+        return self._close_partials(part)
+
+    def score_deflate(self, X2, A, B, wA, wB, rowcnt, out) -> Optional[torch.Tensor]:
+        """Fused K3+K6; returns None when the row does not fit (caller then uses score + deflate)."""
+        part = self.empty(self.n_partials)
+        rc = self._fn("score_deflate", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), _ptr(part), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "score_deflate")
+        return self._close_partials(part)
+
+    # -- K4/K5/K7/K11 small algebra ----------------------------------------------------------
+    def gram_tn(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """C = A^T B for 2-D row-major views (unit inner stride) sharing the leading dimension."""
+        if A.dim() == 1:
+            A = A.unsqueeze(1)
+        if B.dim() == 1:
+            B = B.unsqueeze(1)
+        assert A.stride(1) == 1 and B.stride(1) == 1 and A.shape[0] == B.shape[0]
+        a, b = A.shape[1], B.shape[1]
+        ws = self._workspace("small", self.lib.cmtfpls_small_workspace_bytes())
+        C = self.empty(a, b)
+        _lib.check(self.lib.cmtfpls_gram_tn_f64(_ptr(A), A.stride(0), a, _ptr(B), B.stride(0), b, A.shape[0], _ptr(C),
+                                                _ptr(ws), ws.numel(), self._stream()), "gram_tn")
+        return C
+
+    def rowdot(self, Y: torch.Tensor, q: torch.Tensor, u_out: torch.Tensor, u_old: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        ws = self._workspace("small", self.lib.cmtfpls_small_workspace_bytes())
+        du2 = self.empty(1) if u_old is not None else None
+        _lib.check(self.lib.cmtfpls_rowdot_f64(_ptr(Y), Y.stride(0), Y.shape[1], Y.shape[0], _ptr(q), _ptr(u_out), _ptr(u_old), _ptr(du2),
+                                               _ptr(ws), ws.numel(), self._stream()), "rowdot")
+        return du2
+
+    def scores_mean(self, Ts: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        nb, I = Ts.shape
+        _lib.check(self.lib.cmtfpls_scores_mean_f64(_ptr(Ts), nb, I, _ptr(out), self._stream()), "scores_mean")
+        return out
+
+    def y_deflate(self, Y: torch.Tensor, T: torch.Tensor, ncols: int, b: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+        ws = self._workspace("small", self.lib.cmtfpls_small_workspace_bytes())
+        ssq = self.empty(1)
+        _lib.check(self.lib.cmtfpls_y_deflate_f64(_ptr(Y), Y.stride(0), Y.shape[1], Y.shape[0], _ptr(T), T.stride(0), ncols, _ptr(b), _ptr(q),
+                                                  _ptr(ssq), _ptr(ws), ws.numel(), self._stream()), "y_deflate")
+        return ssq

@@ -1,0 +1,83 @@
+"""``ctPLS``: coupled tensor PLS over a list of X blocks that share the sample mode and one score
+matrix (reference cmtf_pls/cmtf.py:15-237), fitted by the MI355X NIPALS engine.
+
+Same surface as the reference: ``fit(Xs, Y) / predict(Xs) / transform(Xs, Y=None) /
+Xs_reconstructed / copy``, Mapping ``[0], [1], [2]`` -> Xs_factors, Y_factors, coef_.
+``Xs_factors[ti][0]`` is the one shared ``factor_T`` array for every block (cmtf.py:61-65).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .tpls import _EstimatorBase, _as_torch_dtype, to_device_copy
+
+
+class ctPLS(_EstimatorBase):
+    """Coupled tensor PLS"""
+
+    def __getitem__(self, index):
+        if index == 0:
+            return self.Xs_factors
+        if index == 1:
+            return self.Y_factors
+        if index == 2:
+            return self.coef_
+        raise IndexError
+
+    def fit(self, Xs, Y, tol=1e-8, max_iter=100, verbose=0):
+        assert isinstance(Xs, list)                                       # cmtf.py:46
+        for X in Xs:
+            assert X.shape[0] == Y.shape[0]                               # cmtf.py:49
+            assert X.ndim >= 2                                            # cmtf.py:50
+        assert Y.ndim <= 2, "Only a matrix (2-mode tensor) Y is acceptable."
+        eng = self._get_engine()
+        dev = eng.be.device
+        Y2 = Y.reshape(-1, 1) if Y.ndim == 1 else Y
+        self.Xs_len = len(Xs)
+        self.Xs_dim = [X.ndim for X in Xs]
+        self.Xs_shape = [tuple(X.shape) for X in Xs]
+        self.Y_shape = tuple(Y2.shape)
+        Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev) for X in Xs]
+        Yd = to_device_copy(Y2, torch.float64, dev)
+        st = eng.fit(Xd, Yd, self.n_components, tol, max_iter, coupled=True, verbose=verbose)
+        del Xd
+        self._state = st
+        self.factor_T = st.T.cpu().numpy()
+        self.Xs_factors = [[self.factor_T] + [L.cpu().numpy() for L in blk.loadings] for blk in st.blocks]
+        self.Y_factors = [st.U.cpu().numpy(), st.Q.cpu().numpy()]
+        self.coef_ = st.coef
+        self.R2Xs = [blk.r2x for blk in st.blocks]
+        self.R2Y = st.r2y
+        self.Xs_mean = [blk.mean.cpu().numpy().reshape(shape[1:]) for blk, shape in zip(st.blocks, self.Xs_shape)]
+        self.Y_mean = st.y_mean.cpu().numpy()
+        self.Xs_hasMiss = [blk.has_miss for blk in st.blocks]
+        if any(self.Xs_hasMiss):
+            print("At least one X has missing values")                    # cmtf.py:78-79
+        self.Xs_miss = [np.isnan(X) if isinstance(X, np.ndarray) else None for X in Xs]
+        self.n_iter_ = list(st.n_iter)
+
+    def _project(self, Xs) -> np.ndarray:
+        assert len(Xs) == self.Xs_len                                     # cmtf.py:144,181
+        for ti, X in enumerate(Xs):
+            if self.Xs_shape[ti][1:] != tuple(X.shape[1:]):
+                raise ValueError(
+                    f"Training X[{ti}] has shape {self.Xs_shape[ti]}, while the new X has shape {tuple(X.shape)}"
+                )
+        eng = self._get_engine()
+        Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device) for X in Xs]
+        return eng.project(self._state, Xd).cpu().numpy()
+
+    def predict(self, Xs):
+        return self._project(Xs) @ self.coef_ @ self.Y_factors[1].T + self.Y_mean      # cmtf.py:177
+
+    def transform(self, Xs, Y=None):
+        X_scores = self._project(Xs)
+        if Y is not None:
+            return X_scores, self._y_scores(X_scores, Y)
+        return X_scores
+
+    def Xs_reconstructed(self):
+        from .util import factors_to_tensor
+
+        return [factors_to_tensor(self.Xs_factors[ti]) + self.Xs_mean[ti] for ti in range(self.Xs_len)]

@@ -1,0 +1,194 @@
+// Small f64 algebra of the NIPALS loop on tall-skinny operands (Y, T, u, q): everything the
+// reference does with BLAS level-1/2 calls between the two X sweeps (tpls.py:100-113).  All sums
+// are two-stage with a fixed order so results are bit-reproducible run to run and rank to rank.
+#include "common.hpp"
+
+namespace cmtfpls {
+
+void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st);
+
+constexpr int kSmallBlocks = 128;
+constexpr int kMaxGramDim = 64;
+constexpr size_t kSmallWsBytes = (size_t)kSmallBlocks * kMaxGramDim * kMaxGramDim * sizeof(double);
+
+// C = A^T B, per-workgroup partials: part[blk][p*b + q]
+__global__ __launch_bounds__(256) void gram_tn_kernel(const double* __restrict__ A, int lda, int a,
+                                                     const double* __restrict__ B, int ldb, int b,
+                                                     int64_t I, double* __restrict__ part) {
+  constexpr int TR = 32;
+  extern __shared__ double lds[];
+  double* As = lds;            // TR x a
+  double* Bs = lds + TR * a;   // TR x b
+  const int ab = a * b;
+  const int64_t rows_per = (I + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+  const int64_t r1 = (r0 + rows_per < I) ? r0 + rows_per : I;
+  double acc[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+  for (int64_t rb = r0; rb < r1; rb += TR) {
+    const int nr = (int)((r1 - rb < TR) ? r1 - rb : TR);
+    for (int idx = threadIdx.x; idx < nr * a; idx += 256) As[idx] = A[(rb + idx / a) * lda + idx % a];
+    for (int idx = threadIdx.x; idx < nr * b; idx += 256) Bs[idx] = B[(rb + idx / b) * ldb + idx % b];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int o = threadIdx.x + s * 256;
+      if (o < ab) {
+        const int p = o / b, q = o % b;
+        double v = acc[s];
+        for (int r = 0; r < nr; ++r) v = fma(As[r * a + p], Bs[r * b + q], v);
+        acc[s] = v;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int o = threadIdx.x + s * 256;
+    if (o < ab) part[(int64_t)blockIdx.x * ab + o] = acc[s];
+  }
+}
+
+// u[i] = Y[i,:] . q ;  optional partial of sum (u_old - u)^2
+__global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ Y, int ldy, int M, int64_t I,
+                                                    const double* __restrict__ q, double* __restrict__ u,
+                                                    const double* __restrict__ u_old, double* __restrict__ part) {
+  __shared__ double red[16];
+  double d2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < I; i += (int64_t)gridDim.x * 256) {
+    const double* yr = Y + i * ldy;
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) s = fma(yr[m], q[m], s);
+    if (u_old) { const double d = u_old[i] - s; d2 = fma(d, d, d2); }
+    u[i] = s;
+  }
+  if (part) {
+    const double s = block_sum(d2, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+  }
+}
+
+// Y[i,m] -= (T[i,:R] . b) q[m]; partial of ||Y||_F^2 afterwards
+__global__ __launch_bounds__(256) void y_deflate_kernel(double* __restrict__ Y, int ldy, int M, int64_t I,
+                                                       const double* __restrict__ T, int ldt, int R,
+                                                       const double* __restrict__ b, const double* __restrict__ q,
+                                                       double* __restrict__ part) {
+  __shared__ double red[16];
+  double ssq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < I; i += (int64_t)gridDim.x * 256) {
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s = fma(T[i * ldt + r], b[r], s);
+    double* yr = Y + i * ldy;
+    for (int m = 0; m < M; ++m) {
+      const double v = yr[m] - s * q[m];
+      yr[m] = v;
+      ssq = fma(v, v, ssq);
+    }
+  }
+  const double s = block_sum(ssq, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// out[0] = sum(in[0..n)) : one workgroup, strided partials then a fixed-order tree
+__global__ __launch_bounds__(1024) void sum_kernel(const double* __restrict__ in, int64_t n, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += in[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// v /= ||v||_2 : one workgroup
+__global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ v, int64_t n, double* __restrict__ nrm) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s = fma(v[i], v[i], s);
+  s = sqrt(block_sum(s, red));
+  for (int64_t i = threadIdx.x; i < n; i += 1024) v[i] = v[i] / s;
+  if (nrm && threadIdx.x == 0) nrm[0] = s;
+}
+
+__global__ __launch_bounds__(256) void colscale_kernel(double* __restrict__ Z, int64_t P, const double* __restrict__ cnt, double n_samples) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < P) Z[c] = (cnt[c] > 0.0) ? Z[c] / cnt[c] * n_samples : 0.0;
+}
+
+__global__ __launch_bounds__(256) void scores_mean_kernel(const double* __restrict__ Ts, int nb, int64_t I, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= I) return;
+  double s = Ts[i];
+  for (int b = 1; b < nb; ++b) s += Ts[(int64_t)b * I + i];
+  out[i] = s / (double)nb;
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+
+size_t cmtfpls_small_workspace_bytes(void) { return kSmallWsBytes; }
+
+int cmtfpls_gram_tn_f64(const double* A, int lda, int a, const double* B, int ldb, int b, int64_t I,
+                        double* C, void* ws, size_t ws_bytes, void* stream) {
+  if (!A || !B || !C || a <= 0 || b <= 0 || a > kMaxGramDim || b > kMaxGramDim || lda < a || ldb < b || I <= 0) {
+    set_error("gram_tn: bad argument (1 <= a, b <= 64)");
+    return CMTFPLS_EINVAL;
+  }
+  if (!ws || ws_bytes < (size_t)kSmallBlocks * a * b * sizeof(double)) { set_error("gram_tn: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = static_cast<double*>(ws);
+  const size_t lds = (size_t)32 * (a + b) * sizeof(double);
+  hipLaunchKernelGGL(gram_tn_kernel, dim3(kSmallBlocks), dim3(256), lds, st, A, lda, a, B, ldb, b, I, part);
+  launch_reduce_rows(part, kSmallBlocks, (int64_t)a * b, C, st);
+  return check_launch("gram_tn");
+}
+
+int cmtfpls_rowdot_f64(const double* Y, int ldy, int M, int64_t I, const double* q, double* u,
+                       const double* u_old, double* du2, void* ws, size_t ws_bytes, void* stream) {
+  if (!Y || !q || !u || M <= 0 || ldy < M || I <= 0 || (u_old && !du2)) { set_error("rowdot: bad argument"); return CMTFPLS_EINVAL; }
+  if (u_old && (!ws || ws_bytes < kSmallBlocks * sizeof(double))) { set_error("rowdot: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = u_old ? static_cast<double*>(ws) : nullptr;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(kSmallBlocks), dim3(256), 0, st, Y, ldy, M, I, q, u, u_old, part);
+  if (u_old) hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, part, (int64_t)kSmallBlocks, du2);
+  return check_launch("rowdot");
+}
+
+int cmtfpls_y_deflate_f64(double* Y, int ldy, int M, int64_t I, const double* T, int ldt, int R,
+                          const double* b, const double* q, double* ssq, void* ws, size_t ws_bytes, void* stream) {
+  if (!Y || !T || !b || !q || !ssq || M <= 0 || ldy < M || R <= 0 || ldt < R || I <= 0) { set_error("y_deflate: bad argument"); return CMTFPLS_EINVAL; }
+  if (!ws || ws_bytes < kSmallBlocks * sizeof(double)) { set_error("y_deflate: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = static_cast<double*>(ws);
+  hipLaunchKernelGGL(y_deflate_kernel, dim3(kSmallBlocks), dim3(256), 0, st, Y, ldy, M, I, T, ldt, R, b, q, part);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, part, (int64_t)kSmallBlocks, ssq);
+  return check_launch("y_deflate");
+}
+
+int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream) {
+  if (!in || !out || n <= 0) { set_error("sum: bad argument"); return CMTFPLS_EINVAL; }
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out);
+  return check_launch("sum");
+}
+
+int cmtfpls_normalize_f64(double* v, int64_t n, double* nrm, void* stream) {
+  if (!v || n <= 0) { set_error("normalize: bad argument"); return CMTFPLS_EINVAL; }
+  hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, nrm);
+  return check_launch("normalize");
+}
+
+int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_samples, void* stream) {
+  if (!Z || !colcnt || P <= 0) { set_error("colscale: bad argument"); return CMTFPLS_EINVAL; }
+  hipLaunchKernelGGL(colscale_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, P, colcnt, n_samples);
+  return check_launch("colscale");
+}
+
+int cmtfpls_scores_mean_f64(const double* Ts, int nb, int64_t I, double* out, void* stream) {
+  if (!Ts || !out || nb <= 0 || I <= 0) { set_error("scores_mean: bad argument"); return CMTFPLS_EINVAL; }
+  hipLaunchKernelGGL(scores_mean_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Ts, nb, I, out);
+  return check_launch("scores_mean");
+}
+
+}  // extern "C"

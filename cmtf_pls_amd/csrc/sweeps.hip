@@ -1,0 +1,580 @@
+// X sweeps: the HBM-bound kernels of the NIPALS loop.  X is C-order (I, P), P = A*B, stored as
+// f32 or f64; every accumulation is f64.  All reads/writes of X are 16-byte vectors along the
+// contiguous trailing-mode fibre when the shape allows (B % (16/sizeof(T)) == 0), scalar otherwise.
+//
+//   colstats / mode0_contract : thread owns columns, loops over rows   -> (row-block x P) partials
+//   center / score / deflate  : one wavefront per row, grid-stride     -> per-row wave reduction
+//   score_deflate             : one workgroup per row, row kept in VGPRs between the two phases
+//
+// Loadings are passed factored (wA, wB); they are staged once per workgroup into LDS and the
+// Khatri-Rao/Kronecker entry w[c] = wA[c / B] * wB[c % B] is formed on the fly.
+#include "common.hpp"
+
+namespace cmtfpls {
+
+// ------------------------------------------------------------------------------------------
+// mode-0 contraction / column statistics
+// ------------------------------------------------------------------------------------------
+constexpr int kContractU = 2;  // 16-byte column groups per thread
+
+struct ContractPlan {
+  int vec;            // 1: vector kernel, 0: scalar kernel
+  int col_tiles;      // gridDim.x
+  int row_blocks;     // gridDim.y  (= number of partial rows in the workspace)
+  int rows_per_block;
+};
+
+static ContractPlan plan_contract(int64_t I, int64_t P, int elem) {
+  ContractPlan p;
+  const int V = 16 / elem;
+  p.vec = (P % V == 0) ? 1 : 0;
+  const int64_t tile = p.vec ? (int64_t)kSweepThreads * V * kContractU : kSweepThreads;
+  p.col_tiles = (int)((P + tile - 1) / tile);
+  int64_t want = (kSweepBlocks + p.col_tiles - 1) / p.col_tiles;   // ~2048 workgroups in all
+  if (want < 1) want = 1;
+  int64_t rpb = (I + want - 1) / want;
+  if (rpb < 16) rpb = 16;                                           // amortise the partial store
+  p.rows_per_block = (int)rpb;
+  p.row_blocks = (int)((I + rpb - 1) / rpb);
+  if (p.row_blocks < 1) p.row_blocks = 1;
+  return p;
+}
+
+// MODE 0: plain (NaN propagates, as np.einsum)  1: NaN -> 0  2: statistics (u == 1, NaN -> 0, count)
+template <typename T, int MODE>
+__global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
+    const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
+    double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block) {
+  constexpr int V = VecOf<T>::N;
+  constexpr int U = kContractU;
+  using VT = typename VecOf<T>::type;
+  const int64_t cbase = (int64_t)blockIdx.x * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  double acc[U][V];
+  double cnt[U][V];
+  bool ok[U];
+#pragma unroll
+  for (int g = 0; g < U; ++g) {
+    ok[g] = cbase + (int64_t)g * kSweepThreads * V < P;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { acc[g][e] = 0.0; cnt[g][e] = 0.0; }
+  }
+  constexpr int RU = 4;
+  int64_t r = r0;
+  for (; r + RU <= r1; r += RU) {
+    VT x[RU][U];
+    double uu[RU];
+#pragma unroll
+    for (int s = 0; s < RU; ++s) {
+      uu[s] = (MODE == 2) ? 1.0 : u[r + s];
+#pragma unroll
+      for (int g = 0; g < U; ++g)
+        if (ok[g]) x[s][g] = *reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V);
+    }
+#pragma unroll
+    for (int s = 0; s < RU; ++s)
+#pragma unroll
+      for (int g = 0; g < U; ++g)
+        if (ok[g]) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const T xv = x[s][g].e[e];
+            if (MODE == 0) {
+              acc[g][e] = fma((double)xv, uu[s], acc[g][e]);
+            } else {
+              const bool obs = (xv == xv);
+              acc[g][e] = fma(obs ? (double)xv : 0.0, uu[s], acc[g][e]);
+              if (MODE == 2) cnt[g][e] += obs ? 1.0 : 0.0;
+            }
+          }
+        }
+  }
+  for (; r < r1; ++r) {
+    const double us = (MODE == 2) ? 1.0 : u[r];
+#pragma unroll
+    for (int g = 0; g < U; ++g)
+      if (ok[g]) {
+        const VT x = *reinterpret_cast<const VT*>(X + r * P + cbase + (int64_t)g * kSweepThreads * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const T xv = x.e[e];
+          if (MODE == 0) {
+            acc[g][e] = fma((double)xv, us, acc[g][e]);
+          } else {
+            const bool obs = (xv == xv);
+            acc[g][e] = fma(obs ? (double)xv : 0.0, us, acc[g][e]);
+            if (MODE == 2) cnt[g][e] += obs ? 1.0 : 0.0;
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int g = 0; g < U; ++g)
+    if (ok[g]) {
+      const int64_t c = cbase + (int64_t)g * kSweepThreads * V;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        part[(int64_t)blockIdx.y * P + c + e] = acc[g][e];
+        if (MODE == 2) cntpart[(int64_t)blockIdx.y * P + c + e] = cnt[g][e];
+      }
+    }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kSweepThreads) void contract_scalar_kernel(
+    const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
+    double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block) {
+  const int64_t c = (int64_t)blockIdx.x * kSweepThreads + threadIdx.x;
+  if (c >= P) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  double acc = 0.0, cnt = 0.0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const T xv = X[r * P + c];
+    const double us = (MODE == 2) ? 1.0 : u[r];
+    if (MODE == 0) {
+      acc = fma((double)xv, us, acc);
+    } else {
+      const bool obs = (xv == xv);
+      acc = fma(obs ? (double)xv : 0.0, us, acc);
+      if (MODE == 2) cnt += obs ? 1.0 : 0.0;
+    }
+  }
+  part[(int64_t)blockIdx.y * P + c] = acc;
+  if (MODE == 2) cntpart[(int64_t)blockIdx.y * P + c] = cnt;
+}
+
+// out[c] = part[0][c] + part[1][c] + ...  (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ part, int nrows,
+                                                         int64_t P, double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= P) return;
+  double s = 0.0;
+  for (int r = 0; r < nrows; ++r) s += part[(int64_t)r * P + c];
+  out[c] = s;
+}
+
+void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st) {
+  const int grid = (int)((P + 255) / 256);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid), dim3(256), 0, st, part, nrows, P, out);
+}
+
+template <typename T, int MODE>
+static int run_contract(const T* X, int64_t I, int64_t P, const double* u, double* out, double* cnt_out,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!X || !out || I <= 0 || P <= 0 || (MODE != 2 && !u) || (MODE == 2 && !cnt_out)) {
+    set_error("mode0_contract/colstats: bad argument");
+    return CMTFPLS_EINVAL;
+  }
+  if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) { set_error("X must be 16-byte aligned"); return CMTFPLS_EINVAL; }
+  const ContractPlan p = plan_contract(I, P, (int)sizeof(T));
+  const size_t need = (size_t)p.row_blocks * (size_t)P * sizeof(double) * (MODE == 2 ? 2 : 1);
+  if (!ws || ws_bytes < need) { set_error("mode0_contract/colstats: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  double* part = static_cast<double*>(ws);
+  double* cntpart = (MODE == 2) ? part + (size_t)p.row_blocks * P : nullptr;
+  const dim3 grid(p.col_tiles, p.row_blocks);
+  if (p.vec)
+    hipLaunchKernelGGL((contract_vec_kernel<T, MODE>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart, p.rows_per_block);
+  else
+    hipLaunchKernelGGL((contract_scalar_kernel<T, MODE>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart, p.rows_per_block);
+  launch_reduce_rows(part, p.row_blocks, P, out, st);
+  if (MODE == 2) launch_reduce_rows(cntpart, p.row_blocks, P, cnt_out, st);
+  return check_launch("mode0_contract");
+}
+
+// ------------------------------------------------------------------------------------------
+// Kronecker index walker: column c -> (j, k) = (c / B, c % B), advanced by a fixed stride
+// ------------------------------------------------------------------------------------------
+struct KronWalk {
+  int j, k, dj, dk, B;
+  __device__ __forceinline__ KronWalk(int64_t c0, int64_t stride, int B_) : B(B_) {
+    j = (int)(c0 / B_);
+    k = (int)(c0 % B_);
+    dj = (int)(stride / B_);
+    dk = (int)(stride % B_);
+  }
+  __device__ __forceinline__ void next() {
+    k += dk;
+    j += dj;
+    if (k >= B) { k -= B; ++j; }
+  }
+};
+
+__device__ __forceinline__ void stage_loadings(double* sA, double* sB, const double* __restrict__ wA,
+                                               const double* __restrict__ wB, int A, int B) {
+  for (int i = threadIdx.x; i < A; i += blockDim.x) sA[i] = wA[i];
+  for (int i = threadIdx.x; i < B; i += blockDim.x) sB[i] = wB[i];
+  __syncthreads();
+}
+static inline size_t loadings_lds_bytes(int A, int B) { return ((size_t)((A + 1) & ~1) + (size_t)((B + 1) & ~1)) * sizeof(double); }
+
+// sum_e x[e] * wB[k + e]   (V consecutive k: never straddles a j boundary because B % V == 0)
+template <typename T, int V, bool MASKED>
+__device__ __forceinline__ double dot_pack(const Pack<T, V>& x, const double* sBk) {
+  double s = 0.0;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    T xv = x.e[e];
+    if (MASKED) xv = (xv == xv) ? xv : (T)0;
+    s = fma((double)xv, sBk[e], s);
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// score: t[i] = sum_c X[i,c] wA[c/B] wB[c%B]      one wavefront per row
+// ------------------------------------------------------------------------------------------
+template <typename T, bool MASKED, bool VEC>
+__global__ __launch_bounds__(kSweepThreads) void score_kernel(
+    const T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ wA,
+    const double* __restrict__ wB, const double* __restrict__ rowcnt, double* __restrict__ t) {
+  extern __shared__ double lds[];
+  double* sA = lds;
+  double* sB = lds + ((A + 1) & ~1);
+  stage_loadings(sA, sB, wA, wB, A, B);
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  using VT = Pack<T, V>;
+  const int lane = threadIdx.x & 63;
+  const int64_t P = (int64_t)A * B;
+  const int64_t nwaves = (int64_t)gridDim.x * (kSweepThreads / kWave);
+  const int64_t step = (int64_t)kWave * V;
+  const int64_t c0 = (int64_t)lane * V;
+  const KronWalk w0(c0, step, B);
+  for (int64_t row = (int64_t)blockIdx.x * (kSweepThreads / kWave) + (threadIdx.x >> 6); row < I; row += nwaves) {
+    const T* __restrict__ xr = X + row * P;
+    double acc = 0.0;
+    KronWalk w = w0;
+    int64_t c = c0;
+    constexpr int UN = 4;
+    for (; c + (UN - 1) * step < P; c += UN * step) {
+      VT x[UN];
+#pragma unroll
+      for (int s = 0; s < UN; ++s) x[s] = *reinterpret_cast<const VT*>(xr + c + s * step);
+#pragma unroll
+      for (int s = 0; s < UN; ++s) {
+        acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x[s], sB + w.k), acc);
+        w.next();
+      }
+    }
+    for (; c < P; c += step) {
+      const VT x = *reinterpret_cast<const VT*>(xr + c);
+      acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x, sB + w.k), acc);
+      w.next();
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) t[row] = MASKED ? acc / rowcnt[row] * (double)P : acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// deflate: X[i,c] -= t[i] wA[c/B] wB[c%B]  (+ sum of squares of what is left)   wavefront per row
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
+    T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ t,
+    const double* __restrict__ wA, const double* __restrict__ wB, double* __restrict__ ssq_part) {
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  double* sA = lds;
+  double* sB = lds + ((A + 1) & ~1);
+  stage_loadings(sA, sB, wA, wB, A, B);
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  using VT = Pack<T, V>;
+  const int lane = threadIdx.x & 63;
+  const int64_t P = (int64_t)A * B;
+  const int64_t nwaves = (int64_t)gridDim.x * (kSweepThreads / kWave);
+  const int64_t step = (int64_t)kWave * V;
+  const int64_t c0 = (int64_t)lane * V;
+  const KronWalk w0(c0, step, B);
+  double ssq = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * (kSweepThreads / kWave) + (threadIdx.x >> 6); row < I; row += nwaves) {
+    T* __restrict__ xr = X + row * P;
+    const double ti = t[row];
+    KronWalk w = w0;
+    int64_t c = c0;
+    constexpr int UN = 4;
+    for (; c + (UN - 1) * step < P; c += UN * step) {
+      VT x[UN];
+#pragma unroll
+      for (int s = 0; s < UN; ++s) x[s] = *reinterpret_cast<const VT*>(xr + c + s * step);
+#pragma unroll
+      for (int s = 0; s < UN; ++s) {
+        const double tw = ti * sA[w.j];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const T nv = (T)fma(-tw, sB[w.k + e], (double)x[s].e[e]);
+          x[s].e[e] = nv;
+          const double d = (nv == nv) ? (double)nv : 0.0;   // NaN (missing) stays NaN, skipped in the norm
+          ssq = fma(d, d, ssq);
+        }
+        *reinterpret_cast<VT*>(xr + c + s * step) = x[s];
+        w.next();
+      }
+    }
+    for (; c < P; c += step) {
+      VT x = *reinterpret_cast<const VT*>(xr + c);
+      const double tw = ti * sA[w.j];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const T nv = (T)fma(-tw, sB[w.k + e], (double)x.e[e]);
+        x.e[e] = nv;
+        const double d = (nv == nv) ? (double)nv : 0.0;
+        ssq = fma(d, d, ssq);
+      }
+      *reinterpret_cast<VT*>(xr + c) = x;
+      w.next();
+    }
+  }
+  if (ssq_part) {
+    const double s = block_sum(ssq, red);
+    if (threadIdx.x == 0) ssq_part[blockIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// center: X[i,c] -= mean[c]; per-row observation counts; sum of squares     wavefront per row
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kSweepThreads) void center_kernel(
+    T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ mean,
+    double* __restrict__ rowcnt, double* __restrict__ ssq_part) {
+  __shared__ double red[16];
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  using VT = Pack<T, V>;
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (kSweepThreads / kWave);
+  const int64_t step = (int64_t)kWave * V;
+  double ssq = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * (kSweepThreads / kWave) + (threadIdx.x >> 6); row < I; row += nwaves) {
+    T* __restrict__ xr = X + row * P;
+    double cnt = 0.0;
+    for (int64_t c = (int64_t)lane * V; c < P; c += step) {
+      VT x = *reinterpret_cast<const VT*>(xr + c);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const T nv = (T)((double)x.e[e] - mean[c + e]);
+        x.e[e] = nv;
+        const bool obs = (nv == nv);
+        cnt += obs ? 1.0 : 0.0;
+        const double d = obs ? (double)nv : 0.0;
+        ssq = fma(d, d, ssq);
+      }
+      *reinterpret_cast<VT*>(xr + c) = x;
+    }
+    cnt = wave_sum(cnt);
+    if (rowcnt && lane == 0) rowcnt[row] = cnt;
+  }
+  if (ssq_part) {
+    const double s = block_sum(ssq, red);
+    if (threadIdx.x == 0) ssq_part[blockIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// score + deflate fused: one workgroup per row, the row stays in registers between the phases
+// ------------------------------------------------------------------------------------------
+template <typename T, bool MASKED, bool VEC, int NV, int MAXT>
+__global__ __launch_bounds__(MAXT) void score_deflate_kernel(
+    T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ wA,
+    const double* __restrict__ wB, const double* __restrict__ rowcnt, double* __restrict__ t,
+    double* __restrict__ ssq_part) {
+  extern __shared__ double lds[];
+  __shared__ double red[2][16];
+  __shared__ double red2[16];
+  double* sA = lds;
+  double* sB = lds + ((A + 1) & ~1);
+  stage_loadings(sA, sB, wA, wB, A, B);
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  using VT = Pack<T, V>;
+  // a row is < 2^31 elements (guarded on the host): 32-bit element offsets from a uniform row base
+  const unsigned P = (unsigned)A * (unsigned)B;
+  const unsigned stride = blockDim.x * V;
+  const unsigned c0 = threadIdx.x * V;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const KronWalk w0(c0, stride, B);   // row independent; re-walked per phase (cheaper than 2*NV registers)
+  double ssq = 0.0;
+  int parity = 0;
+  for (int64_t row = blockIdx.x; row < I; row += gridDim.x, parity ^= 1) {
+    T* __restrict__ xr = X + row * (int64_t)P;
+    VT x[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+      if (c0 + n * stride < P) x[n] = *reinterpret_cast<const VT*>(xr + c0 + n * stride);
+    double acc = 0.0;
+    {
+      KronWalk w = w0;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        if (c0 + n * stride < P) acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x[n], sB + w.k), acc);
+        w.next();
+        if (NV > 4) __builtin_amdgcn_sched_barrier(0);   // keep live temporaries low: the row owns the VGPRs
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[parity][wv] = acc;
+    __syncthreads();
+    double ti = 0.0;
+    for (int w = 0; w < nw; ++w) ti += red[parity][w];
+    if (MASKED) ti = ti / rowcnt[row] * (double)P;
+    if (threadIdx.x == 0) t[row] = ti;
+    {
+      KronWalk w = w0;
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        if (c0 + n * stride < P) {
+          const double tw = ti * sA[w.j];
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const T nv = (T)fma(-tw, sB[w.k + e], (double)x[n].e[e]);
+            x[n].e[e] = nv;
+            const double d = (nv == nv) ? (double)nv : 0.0;
+            ssq = fma(d, d, ssq);
+          }
+          *reinterpret_cast<VT*>(xr + c0 + n * stride) = x[n];
+        }
+        w.next();
+        if (NV > 4) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (ssq_part) {
+    const double s = block_sum(ssq, red2);
+    if (threadIdx.x == 0) ssq_part[blockIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static bool vec_ok(const T* X, int B) {
+  return (B % VecOf<T>::N == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+}
+static bool shape_ok(int64_t I, int A, int B) { return I > 0 && A > 0 && B > 0; }
+static constexpr size_t kMaxLoadingsLds = 96 * 1024;
+
+template <typename T>
+static int run_score(const T* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                     const double* rowcnt, double* t, hipStream_t st) {
+  if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("score: bad argument"); return CMTFPLS_EINVAL; }
+  const size_t lds = loadings_lds_bytes(A, B);
+  if (lds > kMaxLoadingsLds) { set_error("score: A + B loadings exceed LDS; choose a more balanced (A, B) split"); return CMTFPLS_EUNSUPPORTED; }
+  const bool v = vec_ok(X, B), m = rowcnt != nullptr;
+  const dim3 g(kSweepBlocks), b(kSweepThreads);
+#define LAUNCH(M, V) hipLaunchKernelGGL((score_kernel<T, M, V>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t)
+  if (m && v) LAUNCH(true, true); else if (m) LAUNCH(true, false); else if (v) LAUNCH(false, true); else LAUNCH(false, false);
+#undef LAUNCH
+  return check_launch("score");
+}
+
+template <typename T>
+static int run_deflate(T* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB,
+                       double* ssq_part, hipStream_t st) {
+  if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("deflate: bad argument"); return CMTFPLS_EINVAL; }
+  const size_t lds = loadings_lds_bytes(A, B);
+  if (lds > kMaxLoadingsLds) { set_error("deflate: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
+  const dim3 g(kSweepBlocks), b(kSweepThreads);
+  if (vec_ok(X, B)) hipLaunchKernelGGL((deflate_kernel<T, true>), g, b, lds, st, X, I, A, B, t, wA, wB, ssq_part);
+  else hipLaunchKernelGGL((deflate_kernel<T, false>), g, b, lds, st, X, I, A, B, t, wA, wB, ssq_part);
+  return check_launch("deflate");
+}
+
+template <typename T>
+static int run_center(T* X, int64_t I, int64_t P, const double* mean, double* rowcnt, double* ssq_part, hipStream_t st) {
+  if (!X || !mean || I <= 0 || P <= 0) { set_error("center: bad argument"); return CMTFPLS_EINVAL; }
+  const dim3 g(kSweepBlocks), b(kSweepThreads);
+  const bool v = (P % VecOf<T>::N == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (v) hipLaunchKernelGGL((center_kernel<T, true>), g, b, 0, st, X, I, P, mean, rowcnt, ssq_part);
+  else hipLaunchKernelGGL((center_kernel<T, false>), g, b, 0, st, X, I, P, mean, rowcnt, ssq_part);
+  return check_launch("center");
+}
+
+template <typename T, bool MASKED, bool VEC>
+static void launch_sd(int nv, int threads, size_t lds, hipStream_t st, T* X, int64_t I, int A, int B,
+                      const double* wA, const double* wB, const double* rowcnt, double* t, double* ssq_part) {
+  const dim3 g(kSweepBlocks), b(threads);
+  if (threads > 256) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 1024>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (nv == 1) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 1, 256>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (nv == 4) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 4, 256>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 256>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+}
+
+template <typename T>
+static int run_score_deflate(T* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                             const double* rowcnt, double* t, double* ssq_part, hipStream_t st) {
+  if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("score_deflate: bad argument"); return CMTFPLS_EINVAL; }
+  const size_t lds = loadings_lds_bytes(A, B);
+  if (lds > kMaxLoadingsLds) { set_error("score_deflate: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
+  const bool v = vec_ok(X, B), m = rowcnt != nullptr;
+  const int V = v ? VecOf<T>::N : 1;
+  const int64_t P = (int64_t)A * B;
+  // 256 threads hold up to 256*V*16 elements of a row in registers; longer rows take 1024 threads
+  int threads = 256, nv = 1;
+  if (P > (int64_t)256 * V * 16) { threads = 1024; nv = 16; }
+  if (P > (int64_t)threads * V * 16) { set_error("score_deflate: row does not fit one workgroup; use score + deflate"); return CMTFPLS_EUNSUPPORTED; }
+  while ((int64_t)threads * V * nv < P) nv *= 4;   // 1, 4, 16
+  if (m && v) launch_sd<T, true, true>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (m) launch_sd<T, true, false>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (v) launch_sd<T, false, true>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else launch_sd<T, false, false>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  return check_launch("score_deflate");
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+
+int cmtfpls_sweep_partials(void) { return kSweepBlocks; }
+
+size_t cmtfpls_mode0_contract_workspace_bytes(int64_t I, int64_t P) {
+  if (I <= 0 || P <= 0) return 0;
+  // the f64 plan never has fewer row blocks than the f32 plan for the same shape: size for both
+  const ContractPlan a = plan_contract(I, P, 4), b = plan_contract(I, P, 8);
+  const int rb = a.row_blocks > b.row_blocks ? a.row_blocks : b.row_blocks;
+  return (size_t)rb * (size_t)P * sizeof(double);
+}
+size_t cmtfpls_colstats_workspace_bytes(int64_t I, int64_t P) { return 2 * cmtfpls_mode0_contract_workspace_bytes(I, P); }
+
+int cmtfpls_colstats_f32(const float* X, int64_t I, int64_t P, double* colsum, double* colcnt, void* ws, size_t n, void* s) {
+  return run_contract<float, 2>(X, I, P, nullptr, colsum, colcnt, ws, n, (hipStream_t)s);
+}
+int cmtfpls_colstats_f64(const double* X, int64_t I, int64_t P, double* colsum, double* colcnt, void* ws, size_t n, void* s) {
+  return run_contract<double, 2>(X, I, P, nullptr, colsum, colcnt, ws, n, (hipStream_t)s);
+}
+int cmtfpls_mode0_contract_f32(const float* X, int64_t I, int64_t P, const double* u, double* Z, int masked, void* ws, size_t n, void* s) {
+  return masked ? run_contract<float, 1>(X, I, P, u, Z, nullptr, ws, n, (hipStream_t)s)
+                : run_contract<float, 0>(X, I, P, u, Z, nullptr, ws, n, (hipStream_t)s);
+}
+int cmtfpls_mode0_contract_f64(const double* X, int64_t I, int64_t P, const double* u, double* Z, int masked, void* ws, size_t n, void* s) {
+  return masked ? run_contract<double, 1>(X, I, P, u, Z, nullptr, ws, n, (hipStream_t)s)
+                : run_contract<double, 0>(X, I, P, u, Z, nullptr, ws, n, (hipStream_t)s);
+}
+int cmtfpls_center_f32(float* X, int64_t I, int64_t P, const double* mean, double* rowcnt, double* ssq_part, void* s) {
+  return run_center<float>(X, I, P, mean, rowcnt, ssq_part, (hipStream_t)s);
+}
+int cmtfpls_center_f64(double* X, int64_t I, int64_t P, const double* mean, double* rowcnt, double* ssq_part, void* s) {
+  return run_center<double>(X, I, P, mean, rowcnt, ssq_part, (hipStream_t)s);
+}
+int cmtfpls_score_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt, double* t, void* s) {
+  return run_score<float>(X, I, A, B, wA, wB, rowcnt, t, (hipStream_t)s);
+}
+int cmtfpls_score_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt, double* t, void* s) {
+  return run_score<double>(X, I, A, B, wA, wB, rowcnt, t, (hipStream_t)s);
+}
+int cmtfpls_deflate_f32(float* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB, double* ssq_part, void* s) {
+  return run_deflate<float>(X, I, A, B, t, wA, wB, ssq_part, (hipStream_t)s);
+}
+int cmtfpls_deflate_f64(double* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB, double* ssq_part, void* s) {
+  return run_deflate<double>(X, I, A, B, t, wA, wB, ssq_part, (hipStream_t)s);
+}
+int cmtfpls_score_deflate_f32(float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt, double* t, double* ssq_part, void* s) {
+  return run_score_deflate<float>(X, I, A, B, wA, wB, rowcnt, t, ssq_part, (hipStream_t)s);
+}
+int cmtfpls_score_deflate_f64(double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt, double* t, double* ssq_part, void* s) {
+  return run_score_deflate<double>(X, I, A, B, wA, wB, rowcnt, t, ssq_part, (hipStream_t)s);
+}
+
+}  // extern "C"

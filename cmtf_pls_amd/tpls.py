@@ -1,0 +1,150 @@
+"""``tPLS``: N-way partial least squares with the reference estimator's surface
+(cmtf_pls/tpls.py:15-189 in meyer-lab/cmtf-pls), fitted by the MI355X NIPALS engine.
+
+Same constructor, ``fit / predict / transform / X_reconstructed / copy``, Mapping protocol
+(``[0], [1], [2]`` -> X_factors, Y_factors, coef_) and fitted attributes; NumPy in, NumPy out.
+Opt-in extras (defaults reproduce the reference): ``dtype`` (storage type of X on the GPU:
+"float32" | "float64" | None = follow the input), ``device``, ``comm`` (sample-mode sharding: each
+rank passes its own rows), ``n_iter_`` (inner iterations executed per component) and
+``original_X / original_Y`` (which the reference's validate.get_q2y reads, validate.py:18-21).
+"""
+from __future__ import annotations
+
+from collections.abc import Mapping
+from copy import copy
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .engine import Comm, NipalsEngine
+
+
+def _as_torch_dtype(dtype, like) -> torch.dtype:
+    """Storage type of X on the GPU: explicit, or float32 only when the input already is float32."""
+    if dtype is None:
+        return torch.float32 if like.dtype in (np.float32, torch.float32) else torch.float64
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    name = dtype if isinstance(dtype, str) else np.dtype(dtype).name
+    return {"float32": torch.float32, "f32": torch.float32, "float64": torch.float64, "f64": torch.float64}[name]
+
+
+def to_device_copy(X, dtype: torch.dtype, device) -> torch.Tensor:
+    """A fresh contiguous device tensor of X (inputs are never modified, tpls.py:74,128,151)."""
+    if isinstance(X, torch.Tensor):
+        out = X.to(device=device, dtype=dtype, copy=True)
+    else:
+        out = torch.from_numpy(np.ascontiguousarray(X)).to(device=device, dtype=dtype, copy=True)
+    return out.contiguous()
+
+
+class _EstimatorBase(Mapping):
+    def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None):
+        super().__init__()
+        self.n_components = n_components
+        self._dtype = dtype
+        self._device = device
+        self._comm = comm
+        self._backend = backend
+        self._engine = None
+
+    def _get_engine(self) -> NipalsEngine:
+        if self._engine is None:
+            if self._backend is None:
+                from .backend import HipBackend   # raises if the GPU or libcmtfpls.so is missing
+
+                self._backend = HipBackend(self._device)
+            self._engine = NipalsEngine(self._backend, self._comm)
+        return self._engine
+
+    def __iter__(self):
+        yield self[0]
+        yield self[1]
+        yield self[2]
+
+    def __len__(self):
+        return 3
+
+    def copy(self):
+        return copy(self)
+
+    # shared Y-side epilogue of transform (tpls.py:167-184, cmtf.py:212-229) -- host NumPy, I' x M only
+    def _y_scores(self, X_scores: np.ndarray, Y) -> np.ndarray:
+        Y = np.array(Y, dtype=float, copy=True)
+        if (Y.ndim != 1) and (Y.ndim != 2):
+            raise ValueError("Only a matrix (2-mode tensor) Y is allowed.")
+        if Y.ndim == 1:
+            Y = Y.reshape((-1, 1))
+        if self.Y_shape[1:] != Y.shape[1:]:
+            raise ValueError(f"Training Y has shape {self.Y_shape}, while the new Y has shape {Y.shape}")
+        Y -= self.Y_mean
+        Q = self.Y_factors[1]
+        Y_scores = np.zeros((Y.shape[0], self.n_components))
+        for a in range(self.n_components):
+            Y_scores[:, a] = Y @ Q[:, a]
+            Y -= X_scores @ self.coef_[:, [a]] @ Q[:, [a]].T
+        return Y_scores
+
+
+class tPLS(_EstimatorBase):
+    """Tensor PLS (single X block of order >= 2)."""
+
+    def __getitem__(self, index):
+        if index == 0:
+            return self.X_factors
+        if index == 1:
+            return self.Y_factors
+        if index == 2:
+            return self.coef_
+        raise IndexError
+
+    def fit(self, X, Y, tol=1e-8, max_iter=100, verbose=0):
+        assert X.shape[0] == Y.shape[0]                                   # tpls.py:46
+        assert Y.ndim <= 2, "Only a matrix (2-mode tensor) Y is acceptable."
+        eng = self._get_engine()
+        dev = eng.be.device
+        self.original_X, self.original_Y = X, Y
+        Y2 = Y.reshape(-1, 1) if Y.ndim == 1 else Y
+        self.X_dim = X.ndim
+        self.X_shape = tuple(X.shape)
+        self.Y_shape = tuple(Y2.shape)
+        Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev)
+        Yd = to_device_copy(Y2, torch.float64, dev)
+        st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose)
+        del Xd
+        blk = st.blocks[0]
+        self._state = st
+        self.X_hasMiss = blk.has_miss
+        if self.X_hasMiss:
+            print("X has missing values")                                 # tpls.py:62-63
+        self.X_miss = np.isnan(X) if isinstance(X, np.ndarray) else None
+        self.X_factors = [st.T.cpu().numpy()] + [L.cpu().numpy() for L in blk.loadings]
+        self.Y_factors = [st.U.cpu().numpy(), st.Q.cpu().numpy()]
+        self.coef_ = st.coef
+        self.R2X = blk.r2x
+        self.R2Y = st.r2y
+        self.X_mean = blk.mean.cpu().numpy().reshape(self.X_shape[1:])
+        self.Y_mean = st.y_mean.cpu().numpy()
+        self.n_iter_ = list(st.n_iter)
+
+    def _project(self, X) -> np.ndarray:
+        if self.X_shape[1:] != tuple(X.shape[1:]):
+            raise ValueError(f"Training X has shape {self.X_shape}, while the new X has shape {tuple(X.shape)}")
+        eng = self._get_engine()
+        Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device)
+        return eng.project(self._state, [Xd]).cpu().numpy()
+
+    def predict(self, X):
+        return self._project(X) @ self.coef_ @ self.Y_factors[1].T + self.Y_mean      # tpls.py:143
+
+    def transform(self, X, Y=None):
+        X_scores = self._project(X)
+        if Y is not None:
+            return X_scores, self._y_scores(X_scores, Y)
+        return X_scores
+
+    def X_reconstructed(self):
+        from .util import factors_to_tensor
+
+        return factors_to_tensor(self.X_factors) + self.X_mean                          # tpls.py:188-189

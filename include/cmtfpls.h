@@ -1,0 +1,135 @@
+/*
+ * cmtfpls.h -- C ABI of the MI355X (gfx950) NIPALS engine for tensor PLS / coupled tensor PLS.
+ *
+ * The reference (meyer-lab/cmtf-pls) has no FFI seam: its hot path is a chain of NumPy / tensorly
+ * calls inside tPLS.fit (cmtf_pls/tpls.py:73-120) and ctPLS.fit (cmtf_pls/cmtf.py:85-140).  Each
+ * entry point below replaces ONE of those call sites (cited per function) and is what a binding on
+ * the reference side would call (INTEGRATION.md shows the ctypes stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch tensor's data_ptr());
+ *   - X is C-order (I, P) where P is the product of all trailing modes: the mode-0 unfolding is a
+ *     free view, every sweep reads contiguous rows;  X is stored as f32 or f64 (suffix), every
+ *     other operand (scores, loadings, Y, sums) is f64;
+ *   - trailing-mode loadings are passed as two vectors wA (length A) and wB (length B), A*B == P,
+ *     meaning w[c] = wA[c / B] * wB[c % B]  (order-3 X: wA = w_J, wB = w_K; a matrix X: A = 1);
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it; nothing here
+ *     allocates, synchronises or throws: scratch comes from the caller (`ws`, size from the
+ *     matching *_workspace_bytes);
+ *   - return value: 0 ok, 1 bad argument, 2 workspace too small, 3 HIP error, 4 unsupported shape.
+ *   - missing values are NaNs stored in-band in X (they persist through deflation exactly as in
+ *     the reference, where NaN - x = NaN).
+ */
+#ifndef CMTFPLS_H
+#define CMTFPLS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMTFPLS_OK 0
+#define CMTFPLS_EINVAL 1
+#define CMTFPLS_EWORKSPACE 2
+#define CMTFPLS_EHIP 3
+#define CMTFPLS_EUNSUPPORTED 4
+
+int cmtfpls_abi_version(void);
+const char* cmtfpls_last_error(void);
+
+/* ---- preprocess: tpls.py:61-71, cmtf.py:74-83 ------------------------------------------------
+ * colstats: colsum[c] = sum over non-NaN i of X[i,c]; colcnt[c] = number of non-NaN i
+ *           (np.nanmean = colsum / colcnt; np.isnan mask counts).  ws >= colstats_workspace_bytes.
+ * center:   X[i,c] -= mean[c] in place (NaN stays NaN); rowcnt[i] (nullable) = non-NaN count of
+ *           row i; ssq_part (nullable, >= center_partials() doubles) = per-block partial sums of
+ *           the squared centred observed entries (||X_c||^2, denominator of calcR2X util.py:14). */
+size_t cmtfpls_colstats_workspace_bytes(int64_t I, int64_t P);
+int cmtfpls_colstats_f32(const float* X, int64_t I, int64_t P, double* colsum, double* colcnt,
+                         void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_colstats_f64(const double* X, int64_t I, int64_t P, double* colsum, double* colcnt,
+                         void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_sweep_partials(void); /* number of doubles every *ssq_part* argument must hold */
+int cmtfpls_center_f32(float* X, int64_t I, int64_t P, const double* mean, double* rowcnt,
+                       double* ssq_part, void* stream);
+int cmtfpls_center_f64(double* X, int64_t I, int64_t P, const double* mean, double* rowcnt,
+                       double* ssq_part, void* stream);
+
+/* ---- K1 mode-0 contraction: np.einsum("i...,i...->...", X, u)  tpls.py:83, cmtf.py:94 --------
+ * Z[c] = sum_i X[i,c] * u[i]   (f64 accumulation, deterministic two-stage sum).
+ * masked != 0: NaN entries contribute 0 (numerator of miss_tensordot, missingvals.py:19);
+ * the I/n_obs rescale is cmtfpls_colscale_f64 so that it can follow a cross-GPU all-reduce. */
+size_t cmtfpls_mode0_contract_workspace_bytes(int64_t I, int64_t P);
+int cmtfpls_mode0_contract_f32(const float* X, int64_t I, int64_t P, const double* u, double* Z,
+                               int masked, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_mode0_contract_f64(const double* X, int64_t I, int64_t P, const double* u, double* Z,
+                               int masked, void* ws, size_t ws_bytes, void* stream);
+/* Z[c] = colcnt[c] > 0 ? Z[c] / colcnt[c] * n_samples : 0     (missingvals.py:17-19) */
+int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_samples, void* stream);
+
+/* ---- K2 rank-1 extraction ----------------------------------------------------------------------
+ * rank1: leading singular pair of the A x B matrix Z: what
+ *   parafac(Z, 1, tol, init="svd", normalize_factors=True)[1]   (tpls.py:86-88, cmtf.py:100-102)
+ * returns for a matrix Z.  wA = u1, wB = v1 (unit norm), sigma[0] = sigma_1; sign: the largest-|.|
+ * entry of wB is positive, wA follows (sigma > 0).  Method: repeated squaring of the Gram matrix of
+ * the smaller side (at most n_squarings, early exit when numerically rank one), then two exact
+ * power steps with Z.  normalize: v /= ||v||_2, the vector case `Z / norm(Z)` (tpls.py:84,
+ * cmtf.py:98) and `q /= norm(q)` (tpls.py:101); nrm (nullable) receives the norm. */
+size_t cmtfpls_rank1_workspace_bytes(int A, int B);
+int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma,
+                      int n_squarings, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_normalize_f64(double* v, int64_t n, double* nrm, void* stream);
+
+/* ---- K3 score contraction: multi_mode_dot(X, [w...], range(1, X.ndim))  tpls.py:97-99 ---------
+ * t[i] = sum_c X[i,c] * wA[c / B] * wB[c % B].
+ * rowcnt != NULL selects the masked form miss_mmodedot (missingvals.py:23-38): NaN entries
+ * contribute 0 and t[i] = dot / rowcnt[i] * P (0/0 = NaN for an empty row, as the reference). */
+int cmtfpls_score_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                      const double* rowcnt, double* t, void* stream);
+int cmtfpls_score_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                      const double* rowcnt, double* t, void* stream);
+
+/* ---- K6 rank-1 deflation: X -= outer([t, w_J, w_K])  tpls.py:109; cmtf.py:130-131 ------------
+ * X[i,c] -= t[i] * wA[c / B] * wB[c % B] in place, one read + one write of X.
+ * ssq_part (nullable, cmtfpls_sweep_partials() doubles): per-block partial sums of the squared
+ * deflated entries, NaNs skipped: ||X_{a+1}||^2 = the numerator of calcR2X (util.py:13) because
+ * X_c - factors_to_tensor(X_factors) IS the deflated tensor at observed positions. */
+int cmtfpls_deflate_f32(float* X, int64_t I, int A, int B, const double* t, const double* wA,
+                        const double* wB, double* ssq_part, void* stream);
+int cmtfpls_deflate_f64(double* X, int64_t I, int A, int B, const double* t, const double* wA,
+                        const double* wB, double* ssq_part, void* stream);
+
+/* ---- K3 + K6 fused (transform / predict inner step, tpls.py:133-142, 156-165) -----------------
+ * per row: t[i] = score (masked form when rowcnt != NULL), then the row is deflated with it while
+ * still in registers.  Returns CMTFPLS_EUNSUPPORTED when a row does not fit one workgroup's
+ * registers (P > 65536 for f32, 32768 for f64): call score + deflate instead. */
+int cmtfpls_score_deflate_f32(float* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                              const double* rowcnt, double* t, double* ssq_part, void* stream);
+int cmtfpls_score_deflate_f64(double* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                              const double* rowcnt, double* t, double* ssq_part, void* stream);
+
+/* ---- K4 / K5 / K7 / K11 small f64 algebra on tall-skinny operands ----------------------------
+ * gram_tn:     C (a x b, row-major) = A^T B over I rows; A is (I x a) with leading dim lda, B is
+ *              (I x b) with ldb.  Y.T @ t (tpls.py:100), T^T T and T^T u (normal equations of the
+ *              lstsq at tpls.py:110-112), Y^T Y.   a, b <= 64.
+ * rowdot:      u[i] = sum_m Y[i*ldy + m] * q[m]  (u = Y @ q, tpls.py:102); when u_old != NULL also
+ *              du2[0] = sum_i (u_old[i] - u[i])^2   (norm(oldU - u), tpls.py:103).
+ * scores_mean: out[i] = (Ts[0][i] + Ts[1][i] + ...) / nb   (np.average(Ts, axis=0), cmtf.py:120).
+ * y_deflate:   Y[i,m] -= (sum_r T[i*ldt + r] * b[r]) * q[m]  (tpls.py:113); ssq[0] = ||Y||_F^2 after.
+ * sum:         out[0] = sum of n doubles in a fixed order (closes every *ssq_part* array). */
+size_t cmtfpls_small_workspace_bytes(void);
+int cmtfpls_gram_tn_f64(const double* A, int lda, int a, const double* B, int ldb, int b, int64_t I,
+                        double* C, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_rowdot_f64(const double* Y, int ldy, int M, int64_t I, const double* q, double* u,
+                       const double* u_old, double* du2, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_scores_mean_f64(const double* Ts, int nb, int64_t I, double* out, void* stream);
+int cmtfpls_y_deflate_f64(double* Y, int ldy, int M, int64_t I, const double* T, int ldt, int R,
+                          const double* b, const double* q, double* ssq, void* ws, size_t ws_bytes,
+                          void* stream);
+int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMTFPLS_H */

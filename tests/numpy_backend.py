@@ -1,0 +1,105 @@
+"""NumPy stand-in for cmtf_pls_amd.backend.HipBackend -- TEST INFRASTRUCTURE ONLY.
+
+It lets the engine's control flow (component / iteration / block loops, sharded reductions, the
+R2X / R2Y identities, the normal-equation solve) run on CPU tensors, so that it can be compared
+with the oracle and exercised with world_size-2 gloo jobs without a GPU.  It is never importable
+from the product package and implements each kernel's contract (include/cmtfpls.h) in plain NumPy.
+"""
+import numpy as np
+import torch
+
+
+def _np(t):
+    return None if t is None else t.numpy()
+
+
+class NumpyBackend:
+    name = "numpy-test"
+    device = torch.device("cpu")
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype)
+
+    zeros = empty
+
+    def colstats(self, X2):
+        x = _np(X2).astype(np.float64)
+        obs = ~np.isnan(x)
+        return torch.from_numpy(np.where(obs, x, 0.0).sum(0)), torch.from_numpy(obs.sum(0).astype(np.float64))
+
+    def center(self, X2, mean, want_rowcnt):
+        x = _np(X2)
+        x[...] = (x.astype(np.float64) - _np(mean)).astype(x.dtype)
+        obs = ~np.isnan(x)
+        rowcnt = torch.from_numpy(obs.sum(1).astype(np.float64)) if want_rowcnt else None
+        return rowcnt, torch.tensor([float(np.sum(np.where(obs, x, 0.0).astype(np.float64) ** 2))], dtype=torch.float64)
+
+    def mode0_contract(self, X2, u, masked, out=None):
+        x = _np(X2).astype(np.float64)
+        if masked:
+            x = np.where(np.isnan(x), 0.0, x)
+        z = torch.from_numpy(x.T @ _np(u))
+        if out is not None:
+            out.copy_(z)
+            return out
+        return z
+
+    def colscale(self, Z, colcnt, n_samples):
+        z, c = _np(Z), _np(colcnt)
+        with np.errstate(all="ignore"):
+            z[...] = np.where(c > 0, z / c * n_samples, 0.0)
+
+    def rank1(self, Z, A, B, wA, wB):
+        U, S, Vt = np.linalg.svd(_np(Z).reshape(A, B), full_matrices=False)
+        u, v = U[:, 0], Vt[0]
+        if v[np.argmax(np.abs(v))] < 0:
+            u, v = -u, -v
+        wA.copy_(torch.from_numpy(u.copy()))
+        wB.copy_(torch.from_numpy(v.copy()))
+
+    def normalize(self, v):
+        v /= torch.linalg.norm(v)
+
+    def _w(self, wA, wB):
+        return np.kron(_np(wA), _np(wB))
+
+    def score(self, X2, A, B, wA, wB, rowcnt, out):
+        x = _np(X2).astype(np.float64)
+        w = self._w(wA, wB)
+        if rowcnt is not None:
+            with np.errstate(all="ignore"):
+                t = np.where(np.isnan(x), 0.0, x) @ w / _np(rowcnt) * w.shape[0]
+        else:
+            t = x @ w
+        out.copy_(torch.from_numpy(t))
+        return out
+
+    def deflate(self, X2, A, B, t, wA, wB):
+        x = _np(X2)
+        x[...] = (x.astype(np.float64) - np.outer(_np(t), self._w(wA, wB))).astype(x.dtype)
+        return torch.tensor([float(np.nansum(x.astype(np.float64) ** 2))], dtype=torch.float64)
+
+    def score_deflate(self, X2, A, B, wA, wB, rowcnt, out):
+        self.score(X2, A, B, wA, wB, rowcnt, out)
+        return self.deflate(X2, A, B, out, wA, wB)
+
+    def gram_tn(self, A, B):
+        if A.dim() == 1:
+            A = A.unsqueeze(1)
+        if B.dim() == 1:
+            B = B.unsqueeze(1)
+        return (A.t() @ B).contiguous()
+
+    def rowdot(self, Y, q, u_out, u_old):
+        u = Y @ q
+        du2 = torch.tensor([float(((u_old - u) ** 2).sum())], dtype=torch.float64) if u_old is not None else None
+        u_out.copy_(u)
+        return du2
+
+    def scores_mean(self, Ts, out):
+        out.copy_(torch.from_numpy(np.average(_np(Ts), axis=0)))
+        return out
+
+    def y_deflate(self, Y, T, ncols, b, q):
+        Y -= torch.outer(T[:, :ncols] @ b, q)
+        return torch.tensor([float((Y ** 2).sum())], dtype=torch.float64)

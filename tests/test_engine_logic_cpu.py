@@ -1,0 +1,125 @@
+"""The engine's control flow against the oracle on CPU (NumPy test backend, tests/numpy_backend.py).
+
+This checks everything in cmtf_pls_amd/engine.py that is NOT a kernel: the loop structure, the
+R2X / R2Y identities that replace the reference's reconstruction passes, the normal-equation form
+of the lstsq, masked scaling, coupled averaging, transform / predict.  Kernel parity is the job of
+the -m gpu tests.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from cmtf_pls_amd import ctPLS, tPLS
+from numpy_backend import NumpyBackend
+
+
+def _canon(W_new, W_ref):
+    """Per-component sign of W_new aligned with W_ref."""
+    s = np.sign(np.sum(W_new * W_ref, axis=0))
+    s[s == 0] = 1
+    return W_new * s
+
+
+def _check_fit(m, fit, block=0, rtol=1e-7):
+    Xf = m.X_factors if hasattr(m, "X_factors") else m.Xs_factors[block]
+    np.testing.assert_allclose(Xf[0], fit.T, rtol=rtol, atol=1e-8)
+    loads = fit.loadings[block]
+    # the product of the trailing loadings is sign-invariant; single loadings up to a paired sign
+    for got, want in zip(Xf[1:], loads):
+        np.testing.assert_allclose(np.abs(got), np.abs(want), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(m.Y_factors[0], fit.U, rtol=rtol, atol=1e-8)
+    np.testing.assert_allclose(m.Y_factors[1], fit.Q, rtol=rtol, atol=1e-8)
+    np.testing.assert_allclose(m.coef_, fit.coef, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-7, atol=1e-9)
+    assert list(m.n_iter_) == list(fit.n_iter)
+
+
+def test_tpls_cfg1_matches_oracle():
+    x, y, _ = O.import_synthetic((200, 10, 8), 4, 3, error=0.1)
+    m = tPLS(3, backend=NumpyBackend())
+    m.fit(x, y)
+    fit = O.fit_tpls(x, y, 3)
+    _check_fit(m, fit)
+    np.testing.assert_allclose(m.R2X, fit.r2x[0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m.X_mean, fit.x_means[0])
+    xt = np.random.default_rng(0).normal(size=(7, 10, 8))
+    np.testing.assert_allclose(m.predict(xt), O.predict(fit, xt), rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(m.transform(x), fit.T, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(m.X_reconstructed(), O.reconstruct(fit), rtol=1e-7, atol=1e-8)
+
+
+def test_tpls_matrix_x_and_1d_y():
+    x, y, _ = O.import_synthetic((60, 30), 1, 4, error=0.05, seed=2)
+    assert y.ndim == 1
+    m = tPLS(4, backend=NumpyBackend())
+    m.fit(x, y)
+    fit = O.fit_tpls(x, y, 4)
+    np.testing.assert_allclose(m.X_factors[0], fit.T, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(m.X_factors[1], fit.loadings[0][0], rtol=1e-7, atol=1e-8)   # vector case: no sign freedom
+    np.testing.assert_allclose(m.R2X, fit.r2x[0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-7, atol=1e-9)
+    xs, ys = m.transform(x, y)
+    oxs, oys = O.transform(fit, x, y)
+    np.testing.assert_allclose(xs, oxs, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(ys, oys, rtol=1e-7, atol=1e-8)
+
+
+def test_tpls_missing_values():
+    rng = np.random.default_rng(5)
+    x, y, _ = O.import_synthetic((50, 8, 6), 3, 3, error=0.1, seed=4)
+    x[rng.random(x.shape) < 0.3] = np.nan
+    m = tPLS(3, backend=NumpyBackend())
+    m.fit(x, y)
+    fit = O.fit_tpls(x, y, 3)
+    assert m.X_hasMiss
+    _check_fit(m, fit, rtol=1e-6)
+    np.testing.assert_allclose(m.R2X, fit.r2x[0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.transform(x), fit.T, rtol=1e-6, atol=1e-8)
+
+
+def test_ctpls_tensor_plus_matrix():
+    x3, y3, cp = O.import_synthetic((64, 8, 12), 3, 4, error=0.05, seed=5)
+    xm = cp.factors[0] @ np.random.default_rng(216).normal(size=(20, 4)).T
+    m = ctPLS(4, backend=NumpyBackend())
+    m.fit([x3, xm], y3)
+    fit = O.fit_ctpls([x3, xm], y3, 4)
+    _check_fit(m, fit, block=0)
+    for b in range(2):
+        np.testing.assert_allclose(m.R2Xs[b], fit.r2x[b], rtol=1e-7, atol=1e-9)
+    assert m.Xs_factors[0][0] is m.Xs_factors[1][0] is m.factor_T
+    np.testing.assert_allclose(m.transform([x3, xm]), fit.T, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(m.predict([x3, xm]), O.predict(fit, [x3, xm]), rtol=1e-7, atol=1e-8)
+
+
+def test_api_surface_and_errors():
+    x, y, _ = O.import_synthetic((30, 6, 5), 2, 2)
+    m = tPLS(2, backend=NumpyBackend())
+    m.fit(x, y)
+    assert len(m) == 3 and m[0] is m.X_factors and m[1] is m.Y_factors and m[2] is m.coef_
+    assert [f is g for f, g in zip(list(m), [m.X_factors, m.Y_factors, m.coef_])] == [True] * 3
+    with pytest.raises(IndexError):
+        m[3]
+    with pytest.raises(ValueError, match="Training X has shape"):
+        m.predict(np.zeros((4, 6, 4)))
+    with pytest.raises(ValueError, match="Training X has shape"):
+        m.transform(np.zeros((4, 5, 5)))
+    with pytest.raises(ValueError, match="Training Y has shape"):
+        m.transform(x, np.zeros((30, 3)))
+    with pytest.raises(ValueError, match="Only a matrix"):
+        m.transform(x, np.zeros((30, 2, 1)))
+    with pytest.raises(AssertionError):
+        tPLS(2, backend=NumpyBackend()).fit(x, y[:-1])
+    with pytest.raises(AssertionError):
+        ctPLS(2, backend=NumpyBackend()).fit(x, y)            # not a list (cmtf.py:46)
+    c = m.copy()
+    assert c is not m and c.X_factors is m.X_factors           # shallow, like copy.copy (tpls.py:41-42)
+    x0 = x.copy()
+    m.predict(x)
+    assert np.array_equal(x, x0)                               # inputs are never modified
+
+
+def test_no_cpu_fallback_in_product_path():
+    from cmtf_pls_amd import _lib
+    x, y, _ = O.import_synthetic((10, 4, 3), 2, 2)
+    with pytest.raises(_lib.CmtfplsError):
+        tPLS(2).fit(x, y)                                      # no GPU here -> must fail loudly

@@ -1,0 +1,234 @@
+"""End-to-end parity of the HIP tPLS / ctPLS against the oracle and the committed golden vectors,
+plus the reference's own property tests (seeded, order-3 shapes) run on the HIP classes.
+
+Tolerances: float64 storage -> the GPU path is the same arithmetic as the oracle up to summation
+order, so factors agree to rtol 1e-7 (component-wise sign canonicalised) and the
+iteration counts are equal; float32 storage of fp32-representable inputs -> rtol 1e-5 (the
+north-star tolerance), iteration counts within +-1 after the first in-place f32 deflation.
+"""
+import os
+
+import numpy as np
+import pytest
+from numpy.linalg import norm
+from numpy.testing import assert_allclose
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import cmtf_pls_amd
+    return cmtf_pls_amd
+
+
+def signs(W, Wref):
+    s = np.sign(np.sum(W * Wref, axis=0))
+    s[s == 0] = 1
+    return s
+
+
+def check_against_oracle(m, fit, rtol, block=0, exact_iters=True):
+    Xf = m.X_factors if hasattr(m, "X_factors") else m.Xs_factors[block]
+    scale = np.abs(fit.T).max()
+    assert_allclose(Xf[0], fit.T, rtol=rtol, atol=rtol * scale)
+    loads = fit.loadings[block]
+    if len(loads) == 2:
+        s = signs(Xf[1], loads[0])
+        assert_allclose(Xf[1] * s, loads[0], rtol=rtol, atol=rtol)
+        assert_allclose(Xf[2] * s, loads[1], rtol=rtol, atol=rtol)   # paired sign: same s for both modes
+    else:
+        assert_allclose(Xf[1], loads[0], rtol=rtol, atol=rtol)
+    assert_allclose(m.Y_factors[0], fit.U, rtol=rtol, atol=rtol * np.abs(fit.U).max())
+    assert_allclose(m.Y_factors[1], fit.Q, rtol=rtol, atol=rtol)
+    assert_allclose(m.coef_, fit.coef, rtol=10 * rtol, atol=10 * rtol * np.abs(fit.coef).max())
+    assert_allclose(m.R2Y, fit.r2y, rtol=rtol, atol=rtol)
+    if exact_iters:
+        assert list(m.n_iter_) == list(fit.n_iter)
+    else:
+        assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
+
+
+@pytest.mark.parametrize("err", [0.0, 0.1])
+def test_tpls_cfg1_f64(api, golden_dir, err):
+    """BASELINE.json configs[0]: synthetic (200,10,8), M=4, R=3."""
+    x, y, _ = O.import_synthetic((200, 10, 8), 4, 3, error=err)
+    m = api.tPLS(3)
+    m.fit(x, y)
+    fit = O.fit_tpls(x, y, 3)
+    check_against_oracle(m, fit, 1e-7)
+    assert_allclose(m.R2X, fit.r2x[0], rtol=1e-8, atol=1e-9)
+    g = np.load(os.path.join(golden_dir, "oracle_tpls_cfg1.npz" if err == 0 else "oracle_tpls_cfg1_noise.npz"))
+    assert_allclose(m.X_factors[0], g["T"], rtol=1e-7, atol=1e-7)
+    assert_allclose(m.predict(g["x_test"]), g["pred_test"], rtol=1e-7, atol=1e-7)
+    assert_allclose(m.transform(g["x_test"]), g["scores_test"], rtol=1e-7, atol=1e-7)
+    if err == 0:
+        assert [n - 1 for n in m.n_iter_] == [6, 35, 1]               # BASELINE.md section 2 (reference run)
+        assert_allclose(m.R2X, [0.715, 0.853, 0.940], atol=6e-4)
+        assert_allclose(m.R2Y, [0.475, 0.800, 1.000], atol=6e-4)
+
+
+def test_tpls_f32_storage_golden(api, golden_dir):
+    g = np.load(os.path.join(golden_dir, "oracle_tpls_f32in.npz"))
+    x, y = g["x"], g["y"]
+    m = api.tPLS(4, dtype="float32")
+    m.fit(x, y)
+    fit = O.fit_tpls(x, y, 4)
+    check_against_oracle(m, fit, 1e-5, exact_iters=False)
+    assert_allclose(m.X_factors[0], g["T"], rtol=1e-5, atol=1e-5 * np.abs(g["T"]).max())
+    assert_allclose(m.R2X, g["r2x0"], rtol=1e-5, atol=1e-6)
+    # float32 inputs select float32 storage on their own
+    m2 = api.tPLS(4)
+    m2.fit(x.astype(np.float32), y.astype(np.float32))
+    assert_allclose(m2.X_factors[0], m.X_factors[0], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-7), ("float32", 2e-5)])
+def test_tpls_nan30_golden(api, golden_dir, dtype, rtol):
+    """missingvals path (BASELINE configs[3] in small): 30 % NaN."""
+    g = np.load(os.path.join(golden_dir, "oracle_tpls_f32in_nan30.npz"))
+    x, y = g["x"], g["y"]
+    m = api.tPLS(4, dtype=dtype)
+    m.fit(x, y)
+    assert m.X_hasMiss
+    fit = O.fit_tpls(x, y, 4)
+    check_against_oracle(m, fit, rtol, exact_iters=(dtype == "float64"))
+    assert_allclose(m.R2X, fit.r2x[0], rtol=rtol, atol=rtol)
+    assert_allclose(m.X_factors[0], g["T"], rtol=rtol, atol=rtol * np.abs(g["T"]).max())
+    xs, ys = m.transform(x, y)
+    assert np.allclose(xs, m.X_factors[0], rtol=10 * rtol, atol=10 * rtol * np.abs(xs).max())      # tests/test_missingvals.py:70-80
+    assert np.allclose(ys, m.Y_factors[0], rtol=10 * rtol, atol=10 * rtol * np.abs(ys).max())
+    miss = np.isnan(x)
+    assert_allclose(m.X_reconstructed()[miss], g["recon"][miss], rtol=100 * rtol, atol=100 * rtol)
+
+
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-7), ("float32", 2e-5)])
+def test_ctpls_golden(api, golden_dir, dtype, rtol):
+    """Coupled tensor + matrix block (BASELINE configs[2] in small)."""
+    g = np.load(os.path.join(golden_dir, "oracle_ctpls_small.npz"))
+    x0, x1, y = g["x0"], g["x1"], g["y"]
+    if dtype == "float32":
+        x0, x1, y = [a.astype(np.float32).astype(np.float64) for a in (x0, x1, y)]
+    m = api.ctPLS(4, dtype=dtype)
+    m.fit([x0, x1], y)
+    fit = O.fit_ctpls([x0, x1], y, 4)
+    check_against_oracle(m, fit, rtol, block=0, exact_iters=(dtype == "float64"))
+    check_against_oracle(m, fit, rtol, block=1, exact_iters=(dtype == "float64"))
+    for b in range(2):
+        assert_allclose(m.R2Xs[b], fit.r2x[b], rtol=rtol, atol=rtol)
+    if dtype == "float64":
+        assert_allclose(m.factor_T, g["T"], rtol=1e-7, atol=1e-7)
+    assert np.allclose(m.factor_T, m.transform([x0, x1]), rtol=10 * rtol, atol=10 * rtol * np.abs(m.factor_T).max())
+    assert_allclose(m.predict([x0, x1]), O.predict(fit, [x0, x1]), rtol=10 * rtol, atol=10 * rtol * np.abs(y).max())
+
+
+def test_tpls_ctpls_equivalence(api):                        # tests/test_cmtf.py:8 (order-3 shape)
+    rng = np.random.default_rng(8)
+    X, Y = rng.random((10, 9, 8)), rng.random((10, 5))
+    a, b = api.tPLS(6), api.ctPLS(6)
+    a.fit(X, Y)
+    b.fit([X], Y)
+    assert np.allclose(a.R2X, b.R2Xs[0])
+
+
+# ---- the reference's property tests on the HIP estimator (tests/test_tpls.py) ----------------
+DIMS, N_RESPONSE, N_LATENT = (100, 38, 65), 4, 8
+
+
+@pytest.fixture(scope="module")
+def standard(api):
+    x, y, cp = O.import_synthetic(DIMS, N_RESPONSE, N_LATENT)
+    m = api.tPLS(N_LATENT)
+    m.fit(x, y)
+    return x, y, cp, m
+
+
+def test_factor_normality(standard):                          # tests/test_tpls.py:31
+    m = standard[3]
+    for f in m.X_factors[1:]:
+        assert_allclose(norm(f, axis=0), 1)
+    assert_allclose(norm(m.Y_factors[1], axis=0), 1)
+
+
+def test_factor_orthogonality(standard):                      # tests/test_tpls.py:41
+    m = standard[3]
+    facs = [f / norm(f, axis=0) for f in m.X_factors]
+    for c1 in range(N_LATENT):
+        for c2 in range(c1 + 1, N_LATENT):
+            prod = 1.0
+            for f in facs:
+                prod *= f[:, c1] @ f[:, c2]
+            assert abs(prod) < 1e-2
+
+
+def test_standard_matches_oracle(standard):
+    x, y, _, m = standard
+    fit = O.fit_tpls(x, y, N_LATENT)
+    check_against_oracle(m, fit, 1e-6)
+
+
+def test_same_x_y(api):                                       # tests/test_tpls.py:84
+    from sklearn.decomposition import PCA
+    x, _, _ = O.import_synthetic((100, 100), N_RESPONSE, N_LATENT)
+    m = api.tPLS(N_LATENT)
+    m.fit(x, x)
+    assert_allclose(m.X_factors[0], m.Y_factors[0], rtol=0, atol=1e-4)
+    assert_allclose(m.X_factors[1], m.Y_factors[1], rtol=0, atol=1e-4)
+    pca = PCA(N_LATENT)
+    scores = pca.fit_transform(x)
+
+    def congruence(A, B):
+        from scipy.optimize import linear_sum_assignment
+        C = np.abs((A / norm(A, axis=0)).T @ (B / norm(B, axis=0)))
+        r, c = linear_sum_assignment(-C)
+        return C[r, c].mean()
+
+    assert congruence(m.X_factors[0], scores) > 0.95
+    assert congruence(m.X_factors[1], pca.components_.T) > 0.95
+
+
+def test_zero_covariance_x(api):                              # tests/test_tpls.py:98
+    x, y, _ = O.import_synthetic(DIMS, N_RESPONSE, N_LATENT)
+    x[:, 0, :] = 1
+    m = api.tPLS(N_LATENT)
+    m.fit(x, y)
+    assert_allclose(m.X_factors[1][0, :], 0)                  # rtol 1e-7, atol 0: exactly zero
+
+
+@pytest.mark.parametrize("n_response", [5, 7])
+def test_increasing_r2(api, n_response):                      # tests/test_tpls.py:132-142 (order-3)
+    X, Y, _ = O.import_synthetic((20, 8, 6), n_response, 5)
+    m = api.tPLS(5)
+    m.fit(X, Y)
+    assert np.all(np.diff(m.R2X) >= -1e-12)
+    assert np.all(np.diff(m.R2Y) >= -1e-12)
+
+
+def test_transform_permuted(api):                             # tests/test_tpls.py:145
+    rng = np.random.default_rng(7)
+    X, Y = rng.random((20, 8, 6)), rng.random((20, 5))
+    m = api.tPLS(4)
+    m.fit(X, Y)
+    order = rng.permutation(20)
+    xs, ys = m.transform(X[order], Y[order])
+    assert np.allclose(xs, m.X_factors[0][order])
+    assert np.allclose(ys, m.Y_factors[0][order])
+
+
+def test_medium_f32_against_oracle(api):
+    """A size where every vector kernel variant and multi-row-block reductions are exercised."""
+    x, y, _ = O.import_synthetic((4096, 64, 48), 16, 6, error=0.1, seed=9)
+    x = x.astype(np.float32).astype(np.float64)
+    y = y.astype(np.float32).astype(np.float64)
+    m = api.tPLS(3, dtype="float32")
+    m.fit(x, y, max_iter=30)
+    fit = O.fit_tpls(x, y, 3, max_iter=30)
+    check_against_oracle(m, fit, 1e-5, exact_iters=False)
+    assert_allclose(m.R2X, fit.r2x[0], rtol=1e-5, atol=1e-6)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

@@ -1,0 +1,280 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point of include/cmtfpls.h against the
+CPU oracle / plain NumPy float64 on the same seeded inputs.
+
+Tolerances (written here, per the floating-point bar): every kernel accumulates in f64 from the
+stored X, so against a float64 computation on the SAME stored values the sums agree to
+rtol 1e-11 (only summation order differs); f32-storage writes (center / deflate) are one rounding
+to f32, checked at rtol 2e-7.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RT = dict(rtol=1e-11, atol=1e-11)
+
+
+@pytest.fixture(scope="module")
+def be():
+    from cmtf_pls_amd.backend import HipBackend
+    return HipBackend("cuda:0")
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to("cuda:0")
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+TDT = {"f32": torch.float32, "f64": torch.float64}
+# (I, A, B): vector path (B % 4 == 0), scalar path (odd B), matrix block (A == 1), long rows
+SHAPES = [(37, 10, 8), (100, 38, 65), (64, 1, 20), (33, 1, 7), (50, 128, 128), (29, 5, 4)]
+
+
+def make_x(shape, dt, nan_frac=0.0, seed=0):
+    rng = np.random.default_rng(seed)
+    I, A, B = shape
+    x = rng.normal(size=(I, A * B))
+    if dt == "f32":
+        x = x.astype(np.float32).astype(np.float64)
+    if nan_frac:
+        x[rng.random(x.shape) < nan_frac] = np.nan
+    return x
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_colstats_and_center(be, shape, dt):
+    x = make_x(shape, dt, nan_frac=0.2, seed=1)
+    x[:, 3] = np.nan                                       # a column with no observation
+    x[5, :] = np.nan                                       # a row with no observation
+    X = dev(x, TDT[dt])
+    colsum, colcnt = be.colstats(X)
+    obs = ~np.isnan(x)
+    np.testing.assert_allclose(host(colsum), np.where(obs, x, 0).sum(0), **RT)
+    assert np.array_equal(host(colcnt), obs.sum(0).astype(float))
+    with np.errstate(all="ignore"):
+        mean = np.where(obs, x, 0).sum(0) / obs.sum(0)
+    mean_d = colsum / colcnt
+    rowcnt, ssq = be.center(X, mean_d, True)
+    want = x - mean
+    if dt == "f32":
+        want = want.astype(np.float32).astype(np.float64)
+    got = host(X).astype(np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), rtol=2e-7 if dt == "f32" else 1e-14, atol=1e-12)
+    assert np.array_equal(host(rowcnt), (~np.isnan(want)).sum(1).astype(float))
+    np.testing.assert_allclose(host(ssq)[0], np.nansum(got ** 2), rtol=1e-11)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape", SHAPES + [(1000, 16, 16)])
+def test_mode0_contract(be, shape, dt, masked):
+    x = make_x(shape, dt, nan_frac=0.3 if masked else 0.0, seed=2)
+    u = np.random.default_rng(3).normal(size=shape[0])
+    X = dev(x, TDT[dt])
+    Z = be.mode0_contract(X, dev(u), masked)
+    if masked:
+        cnt = (~np.isnan(x)).sum(0).astype(float)
+        be.colscale(Z, dev(cnt), float(shape[0]))
+        want = O.masked_mode0_contract(x, u)
+    else:
+        want = O.mode0_contract(x, u)
+    np.testing.assert_allclose(host(Z), want, **RT)
+
+
+def test_mode0_contract_nan_propagates_when_unmasked(be):
+    x = make_x((20, 4, 4), "f64", seed=4)
+    x[3, 5] = np.nan
+    Z = host(be.mode0_contract(dev(x), dev(np.ones(20)), False))
+    assert np.isnan(Z[5]) and not np.isnan(np.delete(Z, 5)).any()      # np.einsum semantics (tpls.py:83)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_score(be, shape, dt, masked):
+    I, A, B = shape
+    x = make_x(shape, dt, nan_frac=0.3 if masked else 0.0, seed=5)
+    if masked:
+        x[2, :] = np.nan                                    # empty row -> NaN score (missingvals.py:37)
+    rng = np.random.default_rng(6)
+    wa, wb = rng.normal(size=A), rng.normal(size=B)
+    X = dev(x, TDT[dt])
+    rowcnt = dev((~np.isnan(x)).sum(1).astype(float)) if masked else None
+    t = host(be.score(X, A, B, dev(wa), dev(wb), rowcnt, be.empty(I)))
+    x3 = x.reshape(I, A, B)
+    want = O.masked_score(x3, [wa, wb]) if masked else O.score_contract(x3, [wa, wb])
+    assert np.array_equal(np.isnan(t), np.isnan(want))
+    np.testing.assert_allclose(np.nan_to_num(t), np.nan_to_num(want), **RT)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_deflate(be, shape, dt):
+    I, A, B = shape
+    x = make_x(shape, dt, nan_frac=0.1, seed=7)
+    rng = np.random.default_rng(8)
+    wa, wb, t = rng.normal(size=A), rng.normal(size=B), rng.normal(size=I)
+    X = dev(x, TDT[dt])
+    ssq = be.deflate(X, A, B, dev(t), dev(wa), dev(wb))
+    want = x - np.outer(t, np.kron(wa, wb))
+    if dt == "f32":
+        want = want.astype(np.float32).astype(np.float64)
+    got = host(X).astype(np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), rtol=2e-7 if dt == "f32" else 1e-14, atol=1e-12)
+    np.testing.assert_allclose(host(ssq)[0], np.nansum(got ** 2), rtol=1e-11)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape", SHAPES + [(9, 64, 64), (5, 256, 256), (3, 200, 75)])
+def test_score_deflate_fused(be, shape, dt, masked):
+    I, A, B = shape
+    x = make_x(shape, dt, nan_frac=0.2 if masked else 0.0, seed=9)
+    rng = np.random.default_rng(10)
+    wa, wb = rng.normal(size=A), rng.normal(size=B)
+    wa /= np.linalg.norm(wa)
+    wb /= np.linalg.norm(wb)
+    X = dev(x, TDT[dt])
+    rowcnt = dev((~np.isnan(x)).sum(1).astype(float)) if masked else None
+    t = be.empty(I)
+    ssq = be.score_deflate(X, A, B, dev(wa), dev(wb), rowcnt, t)
+    if ssq is None:
+        assert (dt == "f64" and A * B > 32768)
+        return
+    x3 = x.reshape(I, A, B)
+    t_want = O.masked_score(x3, [wa, wb]) if masked else O.score_contract(x3, [wa, wb])
+    np.testing.assert_allclose(host(t), t_want, **RT)
+    want = x - np.outer(t_want, np.kron(wa, wb))
+    if dt == "f32":
+        want = want.astype(np.float32).astype(np.float64)
+    got = host(X).astype(np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), rtol=3e-7 if dt == "f32" else 1e-13, atol=1e-10)
+    np.testing.assert_allclose(host(ssq)[0], np.nansum(got ** 2), rtol=1e-11)
+
+
+def _svd_pair(Z):
+    U, S, Vt = np.linalg.svd(Z, full_matrices=False)
+    u, v = U[:, 0], Vt[0]
+    if v[np.argmax(np.abs(v))] < 0:
+        u, v = -u, -v
+    return u, v, S
+
+
+@pytest.mark.parametrize("shape", [(10, 8), (8, 10), (128, 128), (38, 65), (200, 7), (1, 9), (9, 1), (256, 256), (17, 300)])
+def test_rank1_matches_lapack(be, shape):
+    A, B = shape
+    rng = np.random.default_rng(11)
+    Z = rng.normal(size=shape) + 3.0 * np.outer(rng.normal(size=A), rng.normal(size=B))
+    wA, wB = be.empty(A), be.empty(B)
+    be.rank1(dev(Z.ravel()), A, B, wA, wB)
+    u, v, S = _svd_pair(Z)
+    np.testing.assert_allclose(host(wA), u, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(host(wB), v, rtol=0, atol=1e-10)
+    # same object as the oracle's restatement of parafac(Z, 1, init="svd") (tpls.py:86-88)
+    fa, fb = O.rank1_factors(Z)
+    np.testing.assert_allclose(host(wA), fa, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(host(wB), fb, rtol=0, atol=1e-9)
+
+
+def test_rank1_close_singular_values_and_zero_rows(be):
+    rng = np.random.default_rng(12)
+    A, B = 40, 30
+    Qa, _ = np.linalg.qr(rng.normal(size=(A, A)))
+    Qb, _ = np.linalg.qr(rng.normal(size=(B, B)))
+    s = np.linspace(1.0, 0.1, B)
+    s[1] = 0.999                                            # s2/s1 = 0.999: plain power iteration would need ~10^4 steps
+    Z = (Qa[:, :B] * s) @ Qb.T
+    Z[0, :] = 0.0                                           # constant slice after centring (tests/test_tpls.py:98)
+    wA, wB = be.empty(A), be.empty(B)
+    be.rank1(dev(Z.ravel()), A, B, wA, wB)
+    u, v, S = _svd_pair(Z)
+    np.testing.assert_allclose(host(wA), u, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(host(wB), v, rtol=0, atol=1e-8)
+    assert host(wA)[0] == 0.0                               # exactly zero, not merely small
+    np.testing.assert_allclose(np.linalg.norm(host(wA)), 1, rtol=1e-14)
+    np.testing.assert_allclose(np.linalg.norm(host(wB)), 1, rtol=1e-14)
+
+
+def test_small_algebra(be):
+    rng = np.random.default_rng(13)
+    I, M, R = 1003, 16, 7
+    Y, T, t, q, b = rng.normal(size=(I, M)), rng.normal(size=(I, R)), rng.normal(size=I), rng.normal(size=M), rng.normal(size=4)
+    Yd, Td = dev(Y), dev(T)
+    np.testing.assert_allclose(host(be.gram_tn(Yd, dev(t))).ravel(), Y.T @ t, **RT)
+    np.testing.assert_allclose(host(be.gram_tn(Td[:, :4], Td[:, :4])), T[:, :4].T @ T[:, :4], **RT)
+    np.testing.assert_allclose(host(be.gram_tn(Yd, Yd)), Y.T @ Y, **RT)
+    u_old = rng.normal(size=I)
+    u = be.empty(I)
+    du2 = be.rowdot(Yd, dev(q), u, dev(u_old))
+    np.testing.assert_allclose(host(u), Y @ q, **RT)
+    np.testing.assert_allclose(host(du2)[0], np.sum((u_old - Y @ q) ** 2), rtol=1e-12)
+    assert be.rowdot(Yd, dev(q), u, None) is None
+    Ts = rng.normal(size=(3, I))
+    np.testing.assert_allclose(host(be.scores_mean(dev(Ts), be.empty(I))), np.average(Ts, axis=0), rtol=1e-15)
+    ssq = be.y_deflate(Yd, Td, 4, dev(b), dev(q))
+    want = Y - np.outer(T[:, :4] @ b, q)
+    np.testing.assert_allclose(host(Yd), want, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(host(ssq)[0], np.sum(want ** 2), rtol=1e-12)
+    v = rng.normal(size=600)
+    vd = dev(v)
+    be.normalize(vd)
+    np.testing.assert_allclose(host(vd), v / np.linalg.norm(v), rtol=1e-14)
+
+
+def test_error_statuses(be):
+    """C-ABI error behaviour: status codes, no exceptions from the library itself."""
+    from cmtf_pls_amd import _lib
+    lib = be.lib
+    X = dev(np.zeros((4, 8)))
+    assert lib.cmtfpls_mode0_contract_f64(X.data_ptr(), 4, 8, None, None, 0, None, 0, None) == 1        # bad argument
+    u, Z = dev(np.zeros(4)), dev(np.zeros(8))
+    assert lib.cmtfpls_mode0_contract_f64(X.data_ptr(), 4, 8, u.data_ptr(), Z.data_ptr(), 0, None, 0, None) == 2   # workspace
+    assert b"workspace" in lib.cmtfpls_last_error()
+    with pytest.raises(_lib.CmtfplsError):
+        _lib.check(2, "x")
+
+
+def test_full_size_properties_cfg2(be):
+    """BASELINE.json configs[1] at full size (65536 x 128 x 128 f32, 4.29 GB) through
+    size-independent properties: linearity of the contraction, |X'|^2 = |X|^2 - |t|^2 for a unit
+    loading, and zero score after deflation with the same loading (idempotence)."""
+    I, A, B = 65536, 128, 128
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    X = torch.randn(I, A * B, device="cuda:0", dtype=torch.float32, generator=g)
+    u1 = torch.randn(I, device="cuda:0", dtype=torch.float64, generator=g)
+    u2 = torch.randn(I, device="cuda:0", dtype=torch.float64, generator=g)
+    Z1 = be.mode0_contract(X, u1, False).clone()
+    Z2 = be.mode0_contract(X, u2, False).clone()
+    Z12 = be.mode0_contract(X, u1 + u2, False)
+    torch.testing.assert_close(Z12, Z1 + Z2, rtol=1e-9, atol=1e-9)
+    # a sub-block against torch f64
+    torch.testing.assert_close(Z1[:64], (X[:, :64].double() * u1[:, None]).sum(0), rtol=1e-9, atol=1e-8)
+    wa = torch.randn(A, device="cuda:0", dtype=torch.float64, generator=g)
+    wb = torch.randn(B, device="cuda:0", dtype=torch.float64, generator=g)
+    wa /= wa.norm()
+    wb /= wb.norm()
+    t = be.score(X, A, B, wa, wb, None, be.empty(I))
+    w = torch.kron(wa, wb)
+    torch.testing.assert_close(t[:256], X[:256].double() @ w, rtol=1e-10, atol=1e-10)
+    ssq0 = float((X[:1024].double() ** 2).sum())            # spot value for the norm bookkeeping below
+    part = be.empty(be.n_partials)
+    _, ssq_all = be.center(X, torch.zeros(A * B, device="cuda:0", dtype=torch.float64), False)
+    ssq_new = be.deflate(X, A, B, t, wa, wb)
+    tt = float((t ** 2).sum())
+    assert abs(float(ssq_new) - (float(ssq_all) - tt)) / float(ssq_all) < 1e-6     # f32 storage rounding
+    t2 = be.score(X, A, B, wa, wb, None, be.empty(I))
+    assert float(t2.abs().max()) < 1e-4 * float(t.abs().max())
+    assert ssq0 > 0 and part.numel() == be.n_partials
