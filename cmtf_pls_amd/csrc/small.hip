@@ -50,6 +50,16 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const double* __restrict__
   }
 }
 
+// C[p*ldc + q] = sum over workgroups of part[blk][p*bc + q]  (fixed order)
+__global__ __launch_bounds__(256) void reduce_block_kernel(const double* __restrict__ part, int nblk, int ac, int bc,
+                                                          double* __restrict__ C, int ldc) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= ac * bc) return;
+  double s = 0.0;
+  for (int r = 0; r < nblk; ++r) s += part[(int64_t)r * ac * bc + o];
+  C[(int64_t)(o / bc) * ldc + (o % bc)] = s;
+}
+
 // u[i] = Y[i,:] . q ;  optional partial of sum (u_old - u)^2
 __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ Y, int ldy, int M, int64_t I,
                                                     const double* __restrict__ q, double* __restrict__ u,
@@ -132,16 +142,23 @@ size_t cmtfpls_small_workspace_bytes(void) { return kSmallWsBytes; }
 
 int cmtfpls_gram_tn_f64(const double* A, int lda, int a, const double* B, int ldb, int b, int64_t I,
                         double* C, void* ws, size_t ws_bytes, void* stream) {
-  if (!A || !B || !C || a <= 0 || b <= 0 || a > kMaxGramDim || b > kMaxGramDim || lda < a || ldb < b || I <= 0) {
-    set_error("gram_tn: bad argument (1 <= a, b <= 64)");
+  if (!A || !B || !C || a <= 0 || b <= 0 || lda < a || ldb < b || I <= 0) {
+    set_error("gram_tn: bad argument");
     return CMTFPLS_EINVAL;
   }
-  if (!ws || ws_bytes < (size_t)kSmallBlocks * a * b * sizeof(double)) { set_error("gram_tn: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  if (!ws || ws_bytes < kSmallWsBytes) { set_error("gram_tn: workspace too small"); return CMTFPLS_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   double* part = static_cast<double*>(ws);
-  const size_t lds = (size_t)32 * (a + b) * sizeof(double);
-  hipLaunchKernelGGL(gram_tn_kernel, dim3(kSmallBlocks), dim3(256), lds, st, A, lda, a, B, ldb, b, I, part);
-  launch_reduce_rows(part, kSmallBlocks, (int64_t)a * b, C, st);
+  // wide operands (e.g. Y with hundreds of responses) are tiled into <= 64 x 64 output blocks
+  for (int a0 = 0; a0 < a; a0 += kMaxGramDim)
+    for (int b0 = 0; b0 < b; b0 += kMaxGramDim) {
+      const int ac = (a - a0 < kMaxGramDim) ? a - a0 : kMaxGramDim;
+      const int bc = (b - b0 < kMaxGramDim) ? b - b0 : kMaxGramDim;
+      const size_t lds = (size_t)32 * (ac + bc) * sizeof(double);
+      hipLaunchKernelGGL(gram_tn_kernel, dim3(kSmallBlocks), dim3(256), lds, st, A + a0, lda, ac, B + b0, ldb, bc, I, part);
+      hipLaunchKernelGGL(reduce_block_kernel, dim3((ac * bc + 255) / 256), dim3(256), 0, st, part, kSmallBlocks, ac, bc,
+                         C + (size_t)a0 * b + b0, b);
+    }
   return check_launch("gram_tn");
 }
 

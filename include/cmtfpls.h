@@ -112,7 +112,7 @@ int cmtfpls_score_deflate_f64(double* X, int64_t I, int A, int B, const double* 
 /* ---- K4 / K5 / K7 / K11 small f64 algebra on tall-skinny operands ----------------------------
  * gram_tn:     C (a x b, row-major) = A^T B over I rows; A is (I x a) with leading dim lda, B is
  *              (I x b) with ldb.  Y.T @ t (tpls.py:100), T^T T and T^T u (normal equations of the
- *              lstsq at tpls.py:110-112), Y^T Y.   a, b <= 64.
+ *              lstsq at tpls.py:110-112), Y^T Y.   Any a, b (tiled 64 x 64).
  * rowdot:      u[i] = sum_m Y[i*ldy + m] * q[m]  (u = Y @ q, tpls.py:102); when u_old != NULL also
  *              du2[0] = sum_i (u_old[i] - u[i])^2   (norm(oldU - u), tpls.py:103).
  * scores_mean: out[i] = (Ts[0][i] + Ts[1][i] + ...) / nb   (np.average(Ts, axis=0), cmtf.py:120).

@@ -216,6 +216,8 @@ def test_small_algebra(be):
     np.testing.assert_allclose(host(be.gram_tn(Yd, dev(t))).ravel(), Y.T @ t, **RT)
     np.testing.assert_allclose(host(be.gram_tn(Td[:, :4], Td[:, :4])), T[:, :4].T @ T[:, :4], **RT)
     np.testing.assert_allclose(host(be.gram_tn(Yd, Yd)), Y.T @ Y, **RT)
+    W = rng.normal(size=(257, 130))                         # wide operand: tiled 64 x 64 inside the call
+    np.testing.assert_allclose(host(be.gram_tn(dev(W), dev(W[:, :70].copy()))), W.T @ W[:, :70], **RT)
     u_old = rng.normal(size=I)
     u = be.empty(I)
     du2 = be.rowdot(Yd, dev(q), u, dev(u_old))
