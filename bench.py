@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- NIPALS iterations/sec (+ sec-to-fit R=10) of the MI355X tPLS engine.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torch.distributed.run,
+one rank per GPU over RCCL).  A *step* is ONE direct-form NIPALS inner iteration of the product
+engine (cmtf_pls_amd.engine.FitRun.iterate = reference tpls.py:80-107): mode-0 contraction (one
+read of X), rank-1 extraction, score contraction (second read of X), Y update, convergence norm
+read back to the host exactly as the reference tests it every iteration.  Inputs are resident in
+HBM before the timed region.  Workload: BASELINE.json configs[1] (X 65536x128x128 f32, Y 65536x16,
+R=10), STRONG scaling: the same X is row-sharded over the N ranks, as the metric is quoted
+("iters/sec on X 65536x128x128 at 1/2/4/8 GPU").
+
+Rank 0 prints ONE JSON line; ``roofline`` is the dominant kernel (the mode-0 contraction launch)
+from HIP events on the launch stream inside the timed region; ``cpu_baseline`` is the NumPy oracle's
+inner loop timed on this host on a row sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", type=int, nargs=3, default=[65536, 128, 128], help="I J K of the whole job")
+    ap.add_argument("--responses", type=int, default=16)
+    ap.add_argument("--components", type=int, default=10)
+    ap.add_argument("--noise", type=float, default=0.1)
+    ap.add_argument("--no-fit", action="store_true", help="skip the sec-to-fit leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-rows", type=int, default=2048)
+    return ap.parse_args()
+
+
+def synth_shard(I_total, J, K, M, L, noise, row0, rows, device, seed=215):
+    """Reference recipe (synthetic.py:59-74): factors from default_rng(seed) in the reference's draw
+    order on the host; the dense shard and its noise are formed on the GPU (4.3 GB cannot be staged
+    through NumPy), X fp32, Y f64."""
+    rng = np.random.default_rng(seed)
+    A0 = rng.normal(0, 1, size=(I_total, L))
+    C = rng.normal(0, 1, size=(M, L))
+    BJ = rng.normal(0, 1, size=(J, L))
+    BK = rng.normal(0, 1, size=(K, L))
+    g = torch.Generator(device=device).manual_seed(1000 + row0)
+    A0d = torch.from_numpy(A0[row0:row0 + rows]).to(device)
+    KR = (torch.from_numpy(BJ).to(device)[:, None, :] * torch.from_numpy(BK).to(device)[None, :, :]).reshape(J * K, L)
+    X = torch.empty(rows, J * K, device=device, dtype=torch.float32)
+    step = 4096
+    for r in range(0, rows, step):
+        blk = (A0d[r:r + step] @ KR.T).float()
+        blk += noise * torch.randn(blk.shape, device=device, dtype=torch.float32, generator=g)
+        X[r:r + step] = blk
+    Y = A0d @ torch.from_numpy(C).to(device).T
+    Y += noise * torch.randn(Y.shape, device=device, dtype=torch.float64, generator=g)
+    return X.view(rows, J, K), Y
+
+
+class EventTimer:
+    """Brackets backend calls with HIP events on the current (launch) stream."""
+
+    def __init__(self, be, names):
+        self.be, self.records, self.on = be, {n: [] for n in names}, False
+        for n in names:
+            setattr(be, n, self._wrap(n, getattr(be, n)))
+
+    def _wrap(self, name, fn):
+        def wrapped(*a, **k):
+            if not self.on:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.records[name].append((e0, e1))
+            return out
+        return wrapped
+
+    def mean_ms(self, name):
+        ev = self.records[name]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+
+
+def cpu_baseline(J, K, M, L, noise, rows, I_total):
+    """The oracle's inner loop (NumPy float64, the reference's arithmetic) on a row sample."""
+    import oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    x, y, _ = O.import_synthetic((rows, J, K), M, L, error=noise)
+    xc, yc = x - x.mean(0), y - y.mean(0)
+    O.nipals_inner_loop(xc, yc, 1)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.nipals_inner_loop(xc, yc, 2)
+        n += 2
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or n >= 200:
+            break
+    per_iter_sample = dt / n
+    per_iter_full = per_iter_sample * (I_total / rows)
+    return {"value": 1.0 / per_iter_full, "unit": "it/s", "cores": int(threads), "kind": "port",
+            "sample": f"oracle.nipals_inner_loop (NumPy f64) on {rows} of {I_total} rows x {J}x{K}, {n} iterations in "
+                      f"{dt:.1f} s = {per_iter_sample*1e3:.1f} ms/iter on the sample, scaled linearly in rows",
+            "host_cpu_count": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from cmtf_pls_amd.backend import HipBackend
+    from cmtf_pls_amd.engine import Comm, NipalsEngine
+
+    I_total, J, K = args.shape
+    M, R = args.responses, args.components
+    assert I_total % world == 0
+    rows = I_total // world
+    X, Y = synth_shard(I_total, J, K, M, R, args.noise, rank * rows, rows, device)
+    be = HipBackend(device)
+    timer = EventTimer(be, ["mode0_contract", "score", "rank1", "gram_tn", "rowdot", "deflate"])
+    eng = NipalsEngine(be, Comm() if world > 1 else None)
+
+    # ---- timed leg: K direct NIPALS iterations of component 0 -------------------------------
+    Xw, Yw = X.clone(), Y.clone()
+    run = eng.begin([Xw], Yw, R, coupled=False)
+    run.start_component(0)
+    for it in range(args.warmup):
+        run.iterate(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        run.iterate(args.warmup + it + 1)          # it > 0: convergence norm computed and read back
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    run.finish_component(0)                        # exercises the deflation sweep once (timed below by events)
+
+    es = X.element_size()
+    xbytes = rows * J * K * es                     # ALGORITHMIC bytes of one X read on this rank
+    kern = {}
+    for name, nbytes in (("mode0_contract", xbytes), ("score", xbytes)):
+        ms = timer.mean_ms(name)
+        kern[name] = {"ms": ms, "alg_GB": nbytes / 1e9, "GBps": nbytes / ms / 1e6 if ms else None}
+    for name in ("rank1", "gram_tn", "rowdot"):
+        kern[name] = {"ms": timer.mean_ms(name)}
+    # deflation sweep (read + write of X), HIP events over 5 launches
+    timer.on = True
+    tz = torch.zeros(rows, dtype=torch.float64, device=device)
+    for _ in range(5):
+        be.deflate(run.X2[0], run.blocks[0].A, run.blocks[0].B, tz, run.wA[0], run.wB[0])
+    torch.cuda.synchronize()
+    timer.on = False
+    ms = timer.mean_ms("deflate")
+    kern["deflate"] = {"ms": ms, "alg_GB": 2 * xbytes / 1e9, "GBps": 2 * xbytes / ms / 1e6}
+    dom = "mode0_contract" if kern["mode0_contract"]["ms"] >= kern["score"]["ms"] else "score"
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                "alg_bytes_per_launch": xbytes, "avg_launch_ms": kern[dom]["ms"]}
+    del Xw, Yw, run
+
+    # ---- sec-to-fit leg (default tol / max_iter, like the reference's fit()) ----------------
+    fit_info = None
+    if not args.no_fit:
+        Xf, Yf = X.clone(), Y.clone()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        st = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False)
+        torch.cuda.synchronize()
+        fit_s = time.perf_counter() - t1
+        fit_info = {"seconds": fit_s, "n_iter": list(st.n_iter), "iters_per_sec_in_fit": sum(st.n_iter) / fit_s,
+                    "R2X_final": float(st.blocks[0].r2x[-1]), "R2Y_final": float(st.r2y[-1]), "tol": 1e-8, "max_iter": 100}
+        del Xf, Yf
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(J, K, M, R, args.noise, args.cpu_rows, I_total)
+
+    if rank == 0:
+        out = {
+            "metric": "nipals_iters_per_sec", "value": args.steps / elapsed, "unit": "it/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: tPLS direct NIPALS iteration, X {I_total}x{J}x{K} f32 "
+                                   f"(f64 accumulation), Y {I_total}x{M}, R={R}, noise {args.noise}",
+                       "rows_per_gpu": rows, "parallelism": f"sample-mode shard x{world}" if world > 1 else "single GPU",
+                       "x_reads_per_step": 2},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "fit": fit_info,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,107 +128,24 @@ class NipalsEngine:
             self.be.rank1(Z, blk.A, blk.B, wA, wB)
 
     # ------------------------------------------------------------------------------------
+    def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool) -> "FitRun":
+        """Preprocess (centre in place) and allocate the per-fit buffers; see FitRun."""
+        return FitRun(self, Xs, Y, n_components, coupled)
+
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
             coupled: bool, verbose: int = 0) -> FitState:
         """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy."""
-        be, comm = self.be, self.comm
-        R = n_components
-        I, M = Y.shape
-        n_tot = torch.tensor([float(I)], dtype=torch.float64, device=Y.device)
-        comm.allreduce(n_tot)
-        n_total = int(round(float(n_tot.item())))
-
-        blocks = [self._prepare_block(X, n_total) for X in Xs]
-        nb = len(blocks)
-        ysum, ycnt = be.colstats(Y)
-        comm.allreduce(ysum)
-        comm.allreduce(ycnt)
-        y_mean = ysum / ycnt                                     # tpls.py:67
-        _, ssqy0 = be.center(Y, y_mean, False)
-        comm.allreduce(ssqy0)
-        ssqy0 = float(ssqy0.item())
-
-        T = be.zeros(I, R)
-        U = be.zeros(I, R)
-        Q = be.zeros(M, R)
-        coef = np.zeros((R, R))
-        r2y = np.zeros(R)
-        for blk in blocks:
-            dims = blk.shape[1:]
-            blk.loadings = [be.zeros(d, R) for d in dims]
-            blk.r2x = np.zeros(R)
-        wA = [be.empty(blk.A) for blk in blocks]
-        wB = [be.empty(blk.B) for blk in blocks]
-        Zs = [be.empty(blk.A * blk.B) for blk in blocks]
-        Ts = be.empty(nb, I)
-        t = be.empty(I)
-        u = be.empty(I)
-        u_new = be.empty(I)
-        q = be.empty(M)
-        n_iter: List[int] = []
-
-        for a in range(R):
-            u.copy_(Y[:, 0])                                     # tpls.py:78
-            executed = 0
+        run = self.begin(Xs, Y, n_components, coupled)
+        for a in range(n_components):
+            run.start_component(a)
             for it in range(max_iter):                           # tpls.py:79
-                executed += 1
-                for b, (blk, X) in enumerate(zip(blocks, Xs)):
-                    X2 = X.view(I, -1)
-                    be.mode0_contract(X2, u, blk.has_miss, out=Zs[b])           # tpls.py:80-83
-                    comm.allreduce(Zs[b])
-                    if blk.has_miss:
-                        be.colscale(Zs[b], blk.colcnt, n_total)                 # missingvals.py:17-19
-                    self._rank1(blk, Zs[b], wA[b], wB[b])                       # tpls.py:84-90
-                    be.score(X2, blk.A, blk.B, wA[b], wB[b], blk.rowcnt if blk.has_miss else None, Ts[b])   # tpls.py:92-99
-                if coupled:
-                    be.scores_mean(Ts, t)                                       # cmtf.py:120
-                else:
-                    t.copy_(Ts[0])
-                qraw = be.gram_tn(Y, t).view(-1)                                # tpls.py:100
-                comm.allreduce(qraw)
-                q.copy_(qraw)
-                be.normalize(q)                                                 # tpls.py:101
-                du2 = be.rowdot(Y, q, u_new, u if it > 0 else None)             # tpls.py:102
-                u, u_new = u_new, u
-                if it > 0:
-                    comm.allreduce(du2)
-                    if math.sqrt(float(du2.item())) < tol:                      # tpls.py:103
-                        if verbose:
-                            print("Comp {}: converged after {} iterations".format(a, it))
-                        break
-            n_iter.append(executed)
-
-            T[:, a].copy_(t)
-            U[:, a].copy_(u)
-            Q[:, a].copy_(q)
-            ssqs = []
-            for b, (blk, X) in enumerate(zip(blocks, Xs)):
-                if len(blk.shape) == 2:
-                    blk.loadings[0][:, a].copy_(wB[b])
-                else:
-                    blk.loadings[0][:, a].copy_(wA[b])
-                    blk.loadings[1][:, a].copy_(wB[b])
-                ssqs.append(be.deflate(X.view(I, -1), blk.A, blk.B, t, wA[b], wB[b]))   # tpls.py:109
-            # inner regression: coef_[:, a] = lstsq(T, u) with columns > a still zero (tpls.py:110-112)
-            Ta = T[:, : a + 1]
-            G = be.gram_tn(Ta, Ta)
-            g = be.gram_tn(Ta, u)
-            packed = torch.cat([G.reshape(-1), g.reshape(-1)] + [s.reshape(-1) for s in ssqs])
-            comm.allreduce(packed)
-            host = packed.cpu().numpy()
-            k = a + 1
-            Gh, gh = host[: k * k].reshape(k, k), host[k * k: k * k + k]
-            bh = np.linalg.lstsq(Gh, gh, rcond=None)[0]
-            coef[:k, a] = bh
-            for b, blk in enumerate(blocks):
-                blk.r2x[a] = 1.0 - host[k * k + k + b] / blk.ssq0                # tpls.py:115-117
-            b_dev = torch.from_numpy(np.ascontiguousarray(bh)).to(Y.device)
-            ssqy = be.y_deflate(Y, T, k, b_dev, q)                               # tpls.py:113
-            comm.allreduce(ssqy)
-            r2y[a] = 1.0 - float(ssqy.item()) / ssqy0                            # tpls.py:118-120
-
-        return FitState(coupled=coupled, n_components=R, blocks=blocks, T=T, U=U, Q=Q, coef=coef, r2y=r2y,
-                        y_mean=y_mean, n_iter=n_iter, n_samples_total=n_total)
+                du = run.iterate(it)
+                if du is not None and du < tol:                  # tpls.py:103 (first pass: oldU = inf)
+                    if verbose:
+                        print("Comp {}: converged after {} iterations".format(a, it))
+                    break
+            run.finish_component(a)
+        return run.result()
 
     # ------------------------------------------------------------------------------------
     def project(self, state: FitState, Xs: List[torch.Tensor]) -> torch.Tensor:
@@ -269,3 +186,114 @@ class NipalsEngine:
                     be.deflate(X.view(I, -1), blk.A, blk.B, t, was[b], wbs[b])
             scores[:, a].copy_(t)
         return scores
+
+
+class FitRun:
+    """One fit in flight: the state between NIPALS iterations.  ``fit`` drives it; bench.py drives
+    ``iterate`` directly so that the timed step IS the product's iteration."""
+
+    def __init__(self, eng: NipalsEngine, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool):
+        be, comm = eng.be, eng.comm
+        self.eng, self.Xs, self.Y, self.R, self.coupled = eng, Xs, Y, n_components, coupled
+        R = n_components
+        I, M = Y.shape
+        self.I, self.M = I, M
+        n_tot = torch.tensor([float(I)], dtype=torch.float64, device=Y.device)
+        comm.allreduce(n_tot)
+        self.n_total = int(round(float(n_tot.item())))
+        self.blocks = [eng._prepare_block(X, self.n_total) for X in Xs]
+        self.X2 = [X.view(I, -1) for X in Xs]
+        ysum, ycnt = be.colstats(Y)
+        comm.allreduce(ysum)
+        comm.allreduce(ycnt)
+        self.y_mean = ysum / ycnt                                 # tpls.py:67
+        _, ssqy0 = be.center(Y, self.y_mean, False)
+        comm.allreduce(ssqy0)
+        self.ssqy0 = float(ssqy0.item())
+        self.T = be.zeros(I, R)
+        self.U = be.zeros(I, R)
+        self.Q = be.zeros(M, R)
+        self.coef = np.zeros((R, R))
+        self.r2y = np.zeros(R)
+        for blk in self.blocks:
+            blk.loadings = [be.zeros(d, R) for d in blk.shape[1:]]
+            blk.r2x = np.zeros(R)
+        self.wA = [be.empty(blk.A) for blk in self.blocks]
+        self.wB = [be.empty(blk.B) for blk in self.blocks]
+        self.Zs = [be.empty(blk.A * blk.B) for blk in self.blocks]
+        self.Ts = be.empty(len(self.blocks), I)
+        self.t = be.empty(I)
+        self.u = be.empty(I)
+        self.u_new = be.empty(I)
+        self.q = be.empty(M)
+        self.n_iter: List[int] = []
+        self._executed = 0
+
+    def start_component(self, a: int) -> None:
+        self.u.copy_(self.Y[:, 0])                                # tpls.py:78
+        self._executed = 0
+
+    def iterate(self, it: int) -> Optional[float]:
+        """One NIPALS inner iteration (tpls.py:80-107).  Returns |u_old - u|_2 (None on the first
+        pass of a component, where the reference compares against +inf)."""
+        be, comm = self.eng.be, self.eng.comm
+        self._executed += 1
+        for b, blk in enumerate(self.blocks):
+            X2 = self.X2[b]
+            be.mode0_contract(X2, self.u, blk.has_miss, out=self.Zs[b])          # tpls.py:80-83
+            comm.allreduce(self.Zs[b])
+            if blk.has_miss:
+                be.colscale(self.Zs[b], blk.colcnt, self.n_total)                # missingvals.py:17-19
+            self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b])             # tpls.py:84-90
+            be.score(X2, blk.A, blk.B, self.wA[b], self.wB[b], blk.rowcnt if blk.has_miss else None, self.Ts[b])   # tpls.py:92-99
+        if self.coupled:
+            be.scores_mean(self.Ts, self.t)                                      # cmtf.py:120
+        else:
+            self.t.copy_(self.Ts[0])
+        qraw = be.gram_tn(self.Y, self.t).view(-1)                               # tpls.py:100
+        comm.allreduce(qraw)
+        self.q.copy_(qraw)
+        be.normalize(self.q)                                                     # tpls.py:101
+        du2 = be.rowdot(self.Y, self.q, self.u_new, self.u if it > 0 else None)  # tpls.py:102
+        self.u, self.u_new = self.u_new, self.u
+        if it == 0:
+            return None
+        comm.allreduce(du2)
+        return math.sqrt(float(du2.item()))                                      # tpls.py:103
+
+    def finish_component(self, a: int) -> None:
+        be, comm = self.eng.be, self.eng.comm
+        self.n_iter.append(self._executed)
+        self.T[:, a].copy_(self.t)
+        self.U[:, a].copy_(self.u)
+        self.Q[:, a].copy_(self.q)
+        ssqs = []
+        for b, blk in enumerate(self.blocks):
+            if len(blk.shape) == 2:
+                blk.loadings[0][:, a].copy_(self.wB[b])
+            else:
+                blk.loadings[0][:, a].copy_(self.wA[b])
+                blk.loadings[1][:, a].copy_(self.wB[b])
+            ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
+        # inner regression: coef_[:, a] = lstsq(T, u) with columns > a still zero (tpls.py:110-112)
+        Ta = self.T[:, : a + 1]
+        G = be.gram_tn(Ta, Ta)
+        g = be.gram_tn(Ta, self.u)
+        packed = torch.cat([G.reshape(-1), g.reshape(-1)] + [s.reshape(-1) for s in ssqs])
+        comm.allreduce(packed)
+        host = packed.cpu().numpy()
+        k = a + 1
+        Gh, gh = host[: k * k].reshape(k, k), host[k * k: k * k + k]
+        bh = np.linalg.lstsq(Gh, gh, rcond=None)[0]
+        self.coef[:k, a] = bh
+        for b, blk in enumerate(self.blocks):
+            blk.r2x[a] = 1.0 - host[k * k + k + b] / blk.ssq0                    # tpls.py:115-117
+        b_dev = torch.from_numpy(np.ascontiguousarray(bh)).to(self.Y.device)
+        ssqy = be.y_deflate(self.Y, self.T, k, b_dev, self.q)                    # tpls.py:113
+        comm.allreduce(ssqy)
+        self.r2y[a] = 1.0 - float(ssqy.item()) / self.ssqy0                      # tpls.py:118-120
+
+    def result(self) -> FitState:
+        return FitState(coupled=self.coupled, n_components=self.R, blocks=self.blocks, T=self.T, U=self.U, Q=self.Q,
+                        coef=self.coef, r2y=self.r2y, y_mean=self.y_mean, n_iter=self.n_iter,
+                        n_samples_total=self.n_total)

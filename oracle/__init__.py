@@ -27,6 +27,7 @@ from .nipals_oracle import (  # noqa: F401
     masked_mode0_contract,
     masked_score,
     mode0_contract,
+    nipals_inner_loop,
     predict,
     rank1_factors,
     score_contract,

@@ -27,7 +27,7 @@ import numpy as np
 __all__ = [
     "OracleFit", "calc_r2x", "cp_factors_to_tensor", "fit_tpls", "fit_ctpls", "mode0_contract",
     "masked_mode0_contract", "masked_score", "score_contract", "rank1_factors", "predict",
-    "transform", "reconstruct",
+    "transform", "reconstruct", "nipals_inner_loop",
 ]
 
 
@@ -318,6 +318,26 @@ def _nipals(blocks, Y, n_components, tol, max_iter, coupled) -> OracleFit:
         y_hat = predict(fit, originals if coupled else originals[0])
         fit.r2y[a] = calc_r2x(Y_in - y_mean, y_hat - y_mean)                   # tpls.py:118-120
     return fit
+
+
+def nipals_inner_loop(Xc: np.ndarray, Yc: np.ndarray, n_iter: int, tol: float = 1e-8):
+    """The bare inner loop of one component on already-centred, NaN-free data (tpls.py:77-107),
+    run for exactly ``n_iter`` iterations: contraction, rank-1 extraction, score, Y update,
+    convergence norm.  This is the unit bench.py's ``cpu_baseline`` times.  Returns (t, w, q, u, du)."""
+    u = Yc[:, 0].copy()
+    old_u = np.full(Yc.shape[0], np.inf)
+    t = w = q = None
+    du = np.inf
+    for _ in range(n_iter):
+        Z = mode0_contract(Xc, u)                                 # tpls.py:83
+        w = rank1_factors(Z, tol)                                 # tpls.py:84-90
+        t = score_contract(Xc, w)                                 # tpls.py:97-99
+        q = Yc.T @ t                                              # tpls.py:100
+        q = q / np.linalg.norm(q)                                 # tpls.py:101
+        u = Yc @ q                                                # tpls.py:102
+        du = np.linalg.norm(old_u - u)                            # tpls.py:103
+        old_u = u.copy()                                          # tpls.py:107
+    return t, w, q, u, du
 
 
 def fit_tpls(X, Y, n_components, tol=1e-8, max_iter=100) -> OracleFit:

@@ -61,3 +61,14 @@ def test_oracle_regression_cfg1(golden_dir, name):
     np.testing.assert_allclose(fit.coef, g["coef"], rtol=1e-8, atol=1e-10)
     assert list(fit.n_iter) == list(g["n_iter"])
     np.testing.assert_allclose(O.predict(fit, g["x_test"]), g["pred_test"], rtol=1e-8, atol=1e-9)
+
+
+def test_inner_loop_is_the_fit_trajectory():
+    """nipals_inner_loop (what bench.py's cpu_baseline times) reproduces component 0 of fit_tpls."""
+    x, y, _ = O.import_synthetic((60, 7, 5), 3, 2, error=0.1, seed=3)
+    fit = O.fit_tpls(x, y, 1)
+    xc, yc = x - x.mean(0), y - y.mean(0)
+    t, w, q, u, du = O.nipals_inner_loop(xc, yc, fit.n_iter[0])
+    np.testing.assert_allclose(t, fit.T[:, 0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(q, fit.Q[:, 0], rtol=1e-12, atol=1e-12)
+    assert du < 1e-8
