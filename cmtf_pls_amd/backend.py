@@ -29,7 +29,7 @@ class HipBackend:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.n_partials = int(self.lib.cmtfpls_sweep_partials())
         self._ws = {}
-        self.rank1_squarings = 24
+        self.rank1_squarings = 30      # budget ceiling: resolves sigma_2/sigma_1 up to 1 - 1e-8
 
     # -- helpers ---------------------------------------------------------------------------
     def _stream(self):
@@ -86,9 +86,12 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_colscale_f64(_ptr(Z), Z.numel(), _ptr(colcnt), float(n_samples), self._stream()), "colscale")
 
     # -- K2: tpls.py:84-90 -------------------------------------------------------------------
-    def rank1(self, Z: torch.Tensor, A: int, B: int, wA: torch.Tensor, wB: torch.Tensor) -> None:
+    def rank1(self, Z: torch.Tensor, A: int, B: int, wA: torch.Tensor, wB: torch.Tensor,
+              info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None) -> None:
+        """info (2 doubles, optional): [converged within the budget, squarings computed]."""
         ws = self._workspace("rank1", self.lib.cmtfpls_rank1_workspace_bytes(A, B))
-        _lib.check(self.lib.cmtfpls_rank1_f64(_ptr(Z), A, B, _ptr(wA), _ptr(wB), None, self.rank1_squarings,
+        _lib.check(self.lib.cmtfpls_rank1_f64(_ptr(Z), A, B, _ptr(wA), _ptr(wB), None, _ptr(info),
+                                              int(n_squarings or self.rank1_squarings),
                                               _ptr(ws), ws.numel(), self._stream()), "rank1")
 
     def normalize(self, v: torch.Tensor) -> None:
@@ -115,7 +118,7 @@ class HipBackend:
         return self._close_partials(part)
 
     # -- K4/K5/K7/K11 small algebra ----------------------------------------------------------
-    def gram_tn(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    def gram_tn(self, A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """C = A^T B for 2-D row-major views (unit inner stride) sharing the leading dimension."""
         if A.dim() == 1:
             A = A.unsqueeze(1)
@@ -124,17 +127,21 @@ class HipBackend:
         assert A.stride(1) == 1 and B.stride(1) == 1 and A.shape[0] == B.shape[0]
         a, b = A.shape[1], B.shape[1]
         ws = self._workspace("small", self.lib.cmtfpls_small_workspace_bytes())
-        C = self.empty(a, b)
+        C = out if out is not None else self.empty(a, b)
+        assert C.numel() == a * b and C.is_contiguous()
         _lib.check(self.lib.cmtfpls_gram_tn_f64(_ptr(A), A.stride(0), a, _ptr(B), B.stride(0), b, A.shape[0], _ptr(C),
                                                 _ptr(ws), ws.numel(), self._stream()), "gram_tn")
         return C
 
-    def rowdot(self, Y: torch.Tensor, q: torch.Tensor, u_out: torch.Tensor, u_old: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    def rowdot(self, Y: torch.Tensor, q: torch.Tensor, u_out: torch.Tensor, u_old: Optional[torch.Tensor],
+               du2: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         ws = self._workspace("small", self.lib.cmtfpls_small_workspace_bytes())
-        du2 = self.empty(1) if u_old is not None else None
-        _lib.check(self.lib.cmtfpls_rowdot_f64(_ptr(Y), Y.stride(0), Y.shape[1], Y.shape[0], _ptr(q), _ptr(u_out), _ptr(u_old), _ptr(du2),
+        if u_old is not None and du2 is None:
+            du2 = self.empty(1)
+        _lib.check(self.lib.cmtfpls_rowdot_f64(_ptr(Y), Y.stride(0), Y.shape[1], Y.shape[0], _ptr(q), _ptr(u_out), _ptr(u_old),
+                                               _ptr(du2) if u_old is not None else None,
                                                _ptr(ws), ws.numel(), self._stream()), "rowdot")
-        return du2
+        return du2 if u_old is not None else None
 
     def scores_mean(self, Ts: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         nb, I = Ts.shape

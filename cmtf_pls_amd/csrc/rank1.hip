@@ -2,13 +2,14 @@
 // i.e. what parafac(Z, 1, init="svd", normalize_factors=True) returns for a matrix
 // (tpls.py:86-88, cmtf.py:100-102).  LAPACK is not available on the device and a plain power
 // iteration converges at (s2/s1)^2 per step, so the Gram matrix G of the smaller side is squared
-// repeatedly instead: after s squarings G^(2^s) is rank one to (s2/s1)^(2^(s+1)), each squaring is
-// one n x n x n f64 product (n <= 256 for the benchmark shapes) spread over n^2/256 workgroups.
-// Scaling between squarings is by an exact power of two taken from the trace, so the iteration is
+// repeatedly instead: after s squarings G^(2^s) is rank one to (s2/s1)^(2^(s+1)); each squaring is
+// one n x n x n f64 product (n <= 256 for the benchmark shapes) spread over (n/16)^2 workgroups
+// that stage their two 16-row panels in LDS with all loads in flight at once.  Scaling between
+// squarings is by an exact power of two taken from the trace, so the iteration is
 // bit-reproducible; it stops early (later launches return at once) when tr(G^2) == tr(G)^2 to
-// 1e-13.  The dominant column of the final G then seeds two exact power steps with Z itself, which
-// also gives exact zeros in the loadings wherever Z has an all-zero row or column
-// (tests/test_tpls.py:98-104 relies on that).
+// 1e-13.  The dominant column of the final G then seeds one exact pass y = M^T seed, x = M y with
+// Z itself (M = Z or Z^T), which also gives exact zeros in the loadings wherever Z has an all-zero
+// row or column (tests/test_tpls.py:98-104 relies on that).
 #include "common.hpp"
 
 namespace cmtfpls {
@@ -16,11 +17,14 @@ namespace cmtfpls {
 constexpr int kTile = 16;
 constexpr int kMaxTiles = 64;   // n <= 1024
 constexpr int kMaxSteps = 48;
+constexpr int kPanelK = 256;    // k-chunk staged in LDS per pass
 
 struct Rank1Ctl {
   double trace[kMaxSteps + 2][kMaxTiles];  // trace[s][tile]: diagonal-tile partial traces of G_s
   int done;                                // set once G is numerically rank one
   int final_buf;                           // which ping-pong buffer holds the final G
+  int steps_used;                          // squarings actually computed
+  int pad;
 };
 
 __device__ __forceinline__ double pow2_scale_from_trace(const double* parts, int nt, double* tr_out) {
@@ -38,18 +42,17 @@ __device__ __forceinline__ double pow2_scale_from_trace(const double* parts, int
 __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* __restrict__ M, int n, int k, int ld,
                                                                 double* __restrict__ C, Rank1Ctl* __restrict__ ctl,
                                                                 int step, int out_buf) {
-  __shared__ double As[kTile][kTile + 1];
-  __shared__ double Bs[kTile][kTile + 1];
+  extern __shared__ double panel[];       // As[16][kc+1] then Bs[16][kc+1]
   __shared__ double diag[kTile];
   __shared__ double s_scale;
   __shared__ int s_done;
-  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTile + tx;
   const int nt = (n + kTile - 1) / kTile;
-  if (tx == 0 && ty == 0) {
+  if (tid == 0) {
     int done = 0;
     double scale = 1.0;
     if (step == 0) {
-      if (blockIdx.x == 0 && blockIdx.y == 0) { ctl->done = 0; ctl->final_buf = -1; }
+      if (blockIdx.x == 0 && blockIdx.y == 0) { ctl->done = 0; ctl->final_buf = -1; ctl->steps_used = 0; }
     } else {
       done = ctl->done;
       if (!done) {
@@ -65,7 +68,10 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
           const double rho = tr1 / (sc0 * sc0 * tr0 * tr0);
           if (!(tr1 > 0.0) || rho >= 1.0 - 1e-13) done = 1;
         }
-        if (done && blockIdx.x == 0 && blockIdx.y == 0) { ctl->done = 1; ctl->final_buf = out_buf ^ 1; }
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+          if (done) { ctl->done = 1; ctl->final_buf = out_buf ^ 1; }
+          else ctl->steps_used = step;
+        }
       }
     }
     s_scale = scale;
@@ -76,13 +82,22 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   const double scale = s_scale;
   const int i0 = blockIdx.y * kTile, j0 = blockIdx.x * kTile;
   double acc = 0.0;
-  for (int kk = 0; kk < k; kk += kTile) {
-    const int col = kk + tx;
-    As[ty][tx] = (i0 + ty < n && col < k) ? M[(int64_t)(i0 + ty) * ld + col] : 0.0;
-    Bs[ty][tx] = (j0 + ty < n && col < k) ? M[(int64_t)(j0 + ty) * ld + col] : 0.0;
+  for (int kk = 0; kk < k; kk += kPanelK) {
+    const int kc = (k - kk < kPanelK) ? k - kk : kPanelK;
+    const int ldp = kc + 1;
+    double* As = panel;
+    double* Bs = panel + kTile * ldp;
+    // stage both 16 x kc panels: consecutive threads read consecutive k (coalesced), all loads in flight
+    for (int idx = tid; idx < kTile * kc; idx += kTile * kTile) {
+      const int r = idx / kc, c = idx - r * kc;
+      As[r * ldp + c] = (i0 + r < n) ? M[(int64_t)(i0 + r) * ld + kk + c] : 0.0;
+      Bs[r * ldp + c] = (j0 + r < n) ? M[(int64_t)(j0 + r) * ld + kk + c] : 0.0;
+    }
     __syncthreads();
-#pragma unroll
-    for (int l = 0; l < kTile; ++l) acc = fma(As[ty][l], Bs[tx][l], acc);
+    const double* ar = As + ty * ldp;
+    const double* br = Bs + tx * ldp;
+#pragma unroll 8
+    for (int l = 0; l < kc; ++l) acc = fma(ar[l], br[l], acc);
     __syncthreads();
   }
   acc *= scale * scale;
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   if (blockIdx.x == blockIdx.y) {
     if (tx == ty) diag[tx] = (i0 + ty < n) ? acc : 0.0;
     __syncthreads();
-    if (tx == 0 && ty == 0) {
+    if (tid == 0) {
       double t = 0.0;
       for (int l = 0; l < kTile; ++l) t += diag[l];
       ctl->trace[step][blockIdx.x] = t;
@@ -105,81 +120,121 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
   Zt[idx] = Z[(int64_t)a * B + b];
 }
 
-// y = Z x (rows of Z over wavefronts) and y = Z^T x (columns over threads), inside one workgroup.
-__device__ void gemv_n(const double* __restrict__ Z, int A, int B, const double* x, double* y) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int j = wv; j < A; j += nw) {
-    double s = 0.0;
-    for (int k = lane; k < B; k += 64) s = fma(Z[(int64_t)j * B + k], x[k], s);
-    s = wave_sum(s);
-    if (lane == 0) y[j] = s;
-  }
-  __syncthreads();
-}
-__device__ void gemv_t(const double* __restrict__ Z, int A, int B, const double* x, double* y) {
-  for (int k = threadIdx.x; k < B; k += blockDim.x) {
-    double s = 0.0;
-    for (int j = 0; j < A; ++j) s = fma(Z[(int64_t)j * B + k], x[j], s);
-    y[k] = s;
-  }
-  __syncthreads();
-}
-__device__ double vec_normalize(double* v, int n, double* red) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s = fma(v[i], v[i], s);
-  s = sqrt(block_sum(s, red));
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v[i] = v[i] / s;
-  __syncthreads();
-  return s;
-}
-
-// From the converged Gram power G (n x n, on the smaller side of Z) to the singular pair.
-__global__ __launch_bounds__(1024) void rank1_finish_kernel(const double* __restrict__ Z, int A, int B,
-                                                           const double* __restrict__ buf0, const double* __restrict__ buf1,
-                                                           const Rank1Ctl* __restrict__ ctl, int last_buf,
-                                                           double* __restrict__ wA, double* __restrict__ wB,
-                                                           double* __restrict__ sigma) {
-  extern __shared__ double lds[];
-  __shared__ double red[3][16];
-  __shared__ int s_arg;
-  double* sa = lds;                    // A
-  double* sb = lds + ((A + 1) & ~1);   // B
-  const bool gram_on_rows = (A <= B);
-  const int n = gram_on_rows ? A : B;
+// ---- finish: seed = dominant column of G (normalised); y = M^T seed; x = M y ------------------
+// F1: every workgroup derives the seed redundantly (n <= 1024: cheap, deterministic), workgroup 0
+//     stores it; each workgroup then produces 32 entries of y with 8 row groups per column.
+__global__ __launch_bounds__(256) void rank1_seed_y_kernel(const double* __restrict__ M, int n, int k,
+                                                          const double* __restrict__ buf0, const double* __restrict__ buf1,
+                                                          const Rank1Ctl* __restrict__ ctl, int last_buf,
+                                                          double* __restrict__ y) {
+  extern __shared__ double seed[];        // n doubles
+  __shared__ double red[16];
+  __shared__ double rsum[8][33];
+  __shared__ double bestv[4];
+  __shared__ int besti[4];
   const int fb = (ctl->final_buf >= 0) ? ctl->final_buf : last_buf;
   const double* G = fb ? buf1 : buf0;
-  // dominant column of G: the one with the largest diagonal entry (first on ties)
-  if (threadIdx.x == 0) {
-    int arg = 0;
-    double best = G[0];
-    for (int i = 1; i < n; ++i) { const double d = G[(int64_t)i * n + i]; if (d > best) { best = d; arg = i; } }
-    s_arg = arg;
+  // argmax of the diagonal (first index on ties)
+  double bv = -1.0;
+  int bi = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double d = G[(int64_t)i * n + i];
+    if (d > bv) { bv = d; bi = i; }
   }
-  __syncthreads();
-  double* seed = gram_on_rows ? sa : sb;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) seed[i] = G[(int64_t)i * n + s_arg];
-  __syncthreads();
-  vec_normalize(seed, n, red[0]);
-  if (gram_on_rows) { gemv_t(Z, A, B, sa, sb); vec_normalize(sb, B, red[1]); }
-  // two exact power steps with Z:  wA = Z wB / |.| ; wB = Z^T wA / |.| ; wA = Z wB / sigma
-  gemv_n(Z, A, B, sb, sa);
-  vec_normalize(sa, A, red[2]);
-  gemv_t(Z, A, B, sa, sb);
-  vec_normalize(sb, B, red[0]);
-  gemv_n(Z, A, B, sb, sa);
-  const double sg = vec_normalize(sa, A, red[1]);
-  // sign rule: largest-|.| entry of the last mode's vector is positive (first on ties)
-  if (threadIdx.x == 0) {
-    int arg = 0;
-    double best = fabs(sb[0]);
-    for (int i = 1; i < B; ++i) { const double d = fabs(sb[i]); if (d > best) { best = d; arg = i; } }
-    s_arg = (sb[arg] < 0.0) ? 1 : 0;
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const double ov = __shfl_xor(bv, m, 64);
+    const int oi = __shfl_xor(bi, m, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
+  if ((threadIdx.x & 63) == 0) { bestv[threadIdx.x >> 6] = bv; besti[threadIdx.x >> 6] = bi; }
   __syncthreads();
-  const double sgn = s_arg ? -1.0 : 1.0;
-  for (int i = threadIdx.x; i < A; i += blockDim.x) wA[i] = sgn * sa[i];
-  for (int i = threadIdx.x; i < B; i += blockDim.x) wB[i] = sgn * sb[i];
-  if (threadIdx.x == 0 && sigma) sigma[0] = sg;
+  bv = bestv[0];
+  bi = besti[0];
+  for (int w = 1; w < 4; ++w)
+    if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
+  // seed = row bi of G (G is bitwise symmetric), normalised
+  double ss = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double g = G[(int64_t)bi * n + i];
+    seed[i] = g;
+    ss = fma(g, g, ss);
+  }
+  const double nrm = sqrt(block_sum(ss, red));
+  for (int i = threadIdx.x; i < n; i += 256) seed[i] = seed[i] / nrm;
+  __syncthreads();
+  // y[c] = sum_j M[j, c] seed[j]
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double s = 0.0;
+  if (c < k)
+    for (int j = ry; j < n; j += 8) s = fma(M[(int64_t)j * k + c], seed[j], s);
+  rsum[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < k) {
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) tot += rsum[g][cx];
+    y[c] = tot;
+  }
+}
+
+// F2: x[j] = sum_c M[j, c] y[c]      one wavefront per row
+__global__ __launch_bounds__(256) void rank1_x_kernel(const double* __restrict__ M, int n, int k,
+                                                     const double* __restrict__ y, double* __restrict__ x) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int c = lane; c < k; c += 64) s = fma(M[(int64_t)j * k + c], y[c], s);
+  s = wave_sum(s);
+  if (lane == 0) x[j] = s;
+}
+
+// F3: normalise x and y, apply the sign rule, write wA / wB / sigma / info
+__global__ __launch_bounds__(1024) void rank1_final_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                          int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
+                                                          double* __restrict__ wA, double* __restrict__ wB,
+                                                          double* __restrict__ sigma, double* __restrict__ info) {
+  __shared__ double red[2][16];
+  __shared__ double bestv[16];
+  __shared__ int besti[16];
+  double sx = 0.0, sy = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) sx = fma(x[i], x[i], sx);
+  for (int i = threadIdx.x; i < k; i += 1024) sy = fma(y[i], y[i], sy);
+  const double nx = sqrt(block_sum(sx, red[0]));
+  const double ny = sqrt(block_sum(sy, red[1]));
+  // sign rule on the LAST mode's vector wB: its largest-|.| entry is positive (first index on ties)
+  const double* vb = x_is_A ? y : x;
+  const int nb = x_is_A ? k : n;
+  double bv = -1.0;
+  int bi = 0;
+  for (int i = threadIdx.x; i < nb; i += 1024) {
+    const double d = fabs(vb[i]);
+    if (d > bv) { bv = d; bi = i; }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const double ov = __shfl_xor(bv, m, 64);
+    const int oi = __shfl_xor(bi, m, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bestv[threadIdx.x >> 6] = bv; besti[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  bv = bestv[0];
+  bi = besti[0];
+  for (int w = 1; w < 16; ++w)
+    if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
+  const double sgn = (vb[bi] < 0.0) ? -1.0 : 1.0;
+  double* ox = x_is_A ? wA : wB;
+  double* oy = x_is_A ? wB : wA;
+  for (int i = threadIdx.x; i < n; i += 1024) ox[i] = sgn * (x[i] / nx);
+  for (int i = threadIdx.x; i < k; i += 1024) oy[i] = sgn * (y[i] / ny);
+  if (threadIdx.x == 0) {
+    // y = M^T seed has norm ~ sigma, x = M y has norm ~ sigma^2: sigma_1 = |x| / |y|
+    if (sigma) sigma[0] = nx / ny;
+    if (info) { info[0] = ctl->done ? 1.0 : 0.0; info[1] = (double)ctl->steps_used; }
+  }
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -192,17 +247,16 @@ extern "C" {
 
 size_t cmtfpls_rank1_workspace_bytes(int A, int B) {
   if (A <= 0 || B <= 0) return 0;
-  const size_t n = (size_t)(A < B ? A : B);
+  const size_t n = (size_t)(A < B ? A : B), k = (size_t)(A < B ? B : A);
   return align_up(sizeof(Rank1Ctl), 256) + 2 * align_up(n * n * sizeof(double), 256) +
-         align_up((size_t)A * B * sizeof(double), 256);
+         align_up((size_t)A * B * sizeof(double), 256) + align_up(n * sizeof(double), 256) + align_up(k * sizeof(double), 256);
 }
 
-int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, int n_squarings,
-                      void* ws, size_t ws_bytes, void* stream) {
+int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
+                      int n_squarings, void* ws, size_t ws_bytes, void* stream) {
   if (!Z || !wA || !wB || A <= 0 || B <= 0) { set_error("rank1: bad argument"); return CMTFPLS_EINVAL; }
-  const int n = A < B ? A : B;
+  const int n = A < B ? A : B, k = A < B ? B : A;
   if (n > kTile * kMaxTiles) { set_error("rank1: min(A, B) > 1024 unsupported"); return CMTFPLS_EUNSUPPORTED; }
-  if ((size_t)((A + 1) & ~1) + (size_t)((B + 1) & ~1) > 8192) { set_error("rank1: A + B > 8192 unsupported"); return CMTFPLS_EUNSUPPORTED; }
   if (n_squarings < 1) n_squarings = 1;
   if (n_squarings > kMaxSteps) n_squarings = kMaxSteps;
   if (!ws || ws_bytes < cmtfpls_rank1_workspace_bytes(A, B)) { set_error("rank1: workspace too small"); return CMTFPLS_EWORKSPACE; }
@@ -215,26 +269,31 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
   double* buf1 = reinterpret_cast<double*>(p);
   p += align_up((size_t)n * n * sizeof(double), 256);
   double* Zt = reinterpret_cast<double*>(p);
+  p += align_up((size_t)A * B * sizeof(double), 256);
+  double* xv = reinterpret_cast<double*>(p);
+  p += align_up((size_t)n * sizeof(double), 256);
+  double* yv = reinterpret_cast<double*>(p);
 
   const double* M0 = Z;   // n x k with n on the smaller side
-  int k0 = B;
   if (A > B) {
     const int64_t tot = (int64_t)A * B;
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Z, A, B, Zt);
     M0 = Zt;
-    k0 = A;
   }
   const int nt = (n + kTile - 1) / kTile;
   const dim3 grid(nt, nt), block(kTile, kTile);
+  auto panel_lds = [](int kdim) { const int kc = kdim < kPanelK ? kdim : kPanelK; return (size_t)2 * kTile * (kc + 1) * sizeof(double); };
   // step 0: G_0 = M0 M0^T -> buf0 ; step s: G_s = scale^2 G_{s-1} G_{s-1}^T -> buf[s & 1]
-  hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, M0, n, k0, k0, buf0, ctl, 0, 0);
+  hipLaunchKernelGGL(syrk_step_kernel, grid, block, panel_lds(k), st, M0, n, k, k, buf0, ctl, 0, 0);
   for (int s = 1; s <= n_squarings; ++s) {
     const double* in = (s & 1) ? buf0 : buf1;
     double* out = (s & 1) ? buf1 : buf0;
-    hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, in, n, n, n, out, ctl, s, s & 1);
+    hipLaunchKernelGGL(syrk_step_kernel, grid, block, panel_lds(n), st, in, n, n, n, out, ctl, s, s & 1);
   }
-  const size_t lds = ((size_t)((A + 1) & ~1) + (size_t)((B + 1) & ~1)) * sizeof(double);
-  hipLaunchKernelGGL(rank1_finish_kernel, dim3(1), dim3(1024), lds, st, Z, A, B, buf0, buf1, ctl, n_squarings & 1, wA, wB, sigma);
+  hipLaunchKernelGGL(rank1_seed_y_kernel, dim3((k + 31) / 32), dim3(256), (size_t)n * sizeof(double), st,
+                     M0, n, k, buf0, buf1, ctl, n_squarings & 1, yv);
+  hipLaunchKernelGGL(rank1_x_kernel, dim3((n + 3) / 4), dim3(256), 0, st, M0, n, k, yv, xv);
+  hipLaunchKernelGGL(rank1_final_kernel, dim3(1), dim3(1024), 0, st, xv, yv, n, k, (A <= B) ? 1 : 0, ctl, wA, wB, sigma, info);
   return check_launch("rank1");
 }
 

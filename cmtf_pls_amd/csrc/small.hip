@@ -50,14 +50,46 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const double* __restrict__
   }
 }
 
-// C[p*ldc + q] = sum over workgroups of part[blk][p*bc + q]  (fixed order)
+// C[p*ldc + q] = sum over workgroups of part[blk][p*bc + q]: one wavefront per output element,
+// lanes stride over the partials, butterfly sum (fixed order -> bit-reproducible)
 __global__ __launch_bounds__(256) void reduce_block_kernel(const double* __restrict__ part, int nblk, int ac, int bc,
                                                           double* __restrict__ C, int ldc) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (o >= ac * bc) return;
   double s = 0.0;
-  for (int r = 0; r < nblk; ++r) s += part[(int64_t)r * ac * bc + o];
-  C[(int64_t)(o / bc) * ldc + (o % bc)] = s;
+  for (int r = lane; r < nblk; r += 64) s += part[(int64_t)r * ac * bc + o];
+  s = wave_sum(s);
+  if (lane == 0) C[(int64_t)(o / bc) * ldc + (o % bc)] = s;
+}
+
+// q = A^T v for a tall A (I x a, a <= 16 per pass) and a vector v: thread per row, the a
+// accumulators stay in registers, one partial row per workgroup.  This is Y.T @ t (tpls.py:100).
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int lda, int a0, int ac,
+                                                    const double* __restrict__ v, int ldv, int64_t I,
+                                                    double* __restrict__ part, int a_total) {
+  __shared__ double red[4][16];
+  double acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < I; i += (int64_t)gridDim.x * 256) {
+    const double vi = v[i * ldv];
+    const double* ar = A + i * lda + a0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (e < ac) acc[e] = fma(ar[e], vi, acc[e]);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const double w = wave_sum(acc[e]);
+    if (lane == 0) red[wv][e] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < ac) {
+    const int e = threadIdx.x;
+    part[(int64_t)blockIdx.x * a_total + a0 + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+  }
 }
 
 // u[i] = Y[i,:] . q ;  optional partial of sum (u_old - u)^2
@@ -149,6 +181,15 @@ int cmtfpls_gram_tn_f64(const double* A, int lda, int a, const double* B, int ld
   if (!ws || ws_bytes < kSmallWsBytes) { set_error("gram_tn: workspace too small"); return CMTFPLS_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   double* part = static_cast<double*>(ws);
+  if (b == 1 && (size_t)kSmallBlocks * a * sizeof(double) <= kSmallWsBytes) {
+    // A^T v: register accumulators, 16 columns of A per pass
+    for (int a0 = 0; a0 < a; a0 += 16) {
+      const int ac = (a - a0 < 16) ? a - a0 : 16;
+      hipLaunchKernelGGL(gemv_t_kernel, dim3(kSmallBlocks), dim3(256), 0, st, A, lda, a0, ac, B, ldb, I, part, a);
+    }
+    hipLaunchKernelGGL(reduce_block_kernel, dim3((a + 3) / 4), dim3(256), 0, st, part, kSmallBlocks, a, 1, C, 1);
+    return check_launch("gram_tn");
+  }
   // wide operands (e.g. Y with hundreds of responses) are tiled into <= 64 x 64 output blocks
   for (int a0 = 0; a0 < a; a0 += kMaxGramDim)
     for (int b0 = 0; b0 < b; b0 += kMaxGramDim) {
@@ -156,7 +197,7 @@ int cmtfpls_gram_tn_f64(const double* A, int lda, int a, const double* B, int ld
       const int bc = (b - b0 < kMaxGramDim) ? b - b0 : kMaxGramDim;
       const size_t lds = (size_t)32 * (ac + bc) * sizeof(double);
       hipLaunchKernelGGL(gram_tn_kernel, dim3(kSmallBlocks), dim3(256), lds, st, A + a0, lda, ac, B + b0, ldb, bc, I, part);
-      hipLaunchKernelGGL(reduce_block_kernel, dim3((ac * bc + 255) / 256), dim3(256), 0, st, part, kSmallBlocks, ac, bc,
+      hipLaunchKernelGGL(reduce_block_kernel, dim3((ac * bc + 3) / 4), dim3(256), 0, st, part, kSmallBlocks, ac, bc,
                          C + (size_t)a0 * b + b0, b);
     }
   return check_launch("gram_tn");

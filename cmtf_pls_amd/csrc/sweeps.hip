@@ -145,18 +145,28 @@ __global__ __launch_bounds__(kSweepThreads) void contract_scalar_kernel(
   if (MODE == 2) cntpart[(int64_t)blockIdx.y * P + c] = cnt;
 }
 
-// out[c] = part[0][c] + part[1][c] + ...  (fixed order: bit-reproducible)
+// out[c] = sum_r part[r][c]: 32 columns x 8 row groups per workgroup, each thread sums every 8th
+// partial row of its column, the 8 group sums are then added in a fixed order (bit-reproducible).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ part, int nrows,
                                                          int64_t P, double* __restrict__ out) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= P) return;
+  __shared__ double red[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int64_t c = (int64_t)blockIdx.x * 32 + cx;
   double s = 0.0;
-  for (int r = 0; r < nrows; ++r) s += part[(int64_t)r * P + c];
-  out[c] = s;
+  if (c < P)
+    for (int r = ry; r < nrows; r += 8) s += part[(int64_t)r * P + c];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < P) {
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) tot += red[g][cx];
+    out[c] = tot;
+  }
 }
 
 void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st) {
-  const int grid = (int)((P + 255) / 256);
+  const int grid = (int)((P + 31) / 32);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid), dim3(256), 0, st, part, nrows, P, out);
 }
 

@@ -116,7 +116,8 @@ class NipalsEngine:
         return BlockState(shape=tuple(X.shape), A=A, B=B, mean=mean, has_miss=has_miss,
                           colcnt=colcnt if has_miss else None, rowcnt=rowcnt, ssq0=float(ssq0.item()))
 
-    def _rank1(self, blk: BlockState, Z: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor) -> None:
+    def _rank1(self, blk: BlockState, Z: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
+               info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None) -> None:
         """tpls.py:84-90: Z / norm(Z) for a vector, leading singular pair for a matrix."""
         if len(blk.shape) > 3:
             raise NotImplementedError("X blocks of order >= 4 (cross-covariance tensor of order >= 3) are not built yet")
@@ -125,7 +126,7 @@ class NipalsEngine:
             self.be.normalize(wB)
             wA.fill_(1.0)
         else:
-            self.be.rank1(Z, blk.A, blk.B, wA, wB)
+            self.be.rank1(Z, blk.A, blk.B, wA, wB, info=info, n_squarings=n_squarings)
 
     # ------------------------------------------------------------------------------------
     def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool) -> "FitRun":
@@ -222,7 +223,13 @@ class FitRun:
         self.wB = [be.empty(blk.B) for blk in self.blocks]
         self.Zs = [be.empty(blk.A * blk.B) for blk in self.blocks]
         self.Ts = be.empty(len(self.blocks), I)
-        self.t = be.empty(I)
+        # one block, no averaging: the score kernel writes t directly (no copy)
+        self.t = self.Ts[0] if (len(self.blocks) == 1 and not coupled) else be.empty(I)
+        # per-iteration status read back in ONE device->host copy: [|du|^2, (converged, squarings) per block]
+        self.status = be.zeros(1 + 2 * len(self.blocks))
+        self.status[1::2] = 1.0
+        self.sq_max = int(getattr(be, "rank1_squarings", 30))
+        self.sq_budget = [self.sq_max] * len(self.blocks)
         self.u = be.empty(I)
         self.u_new = be.empty(I)
         self.q = be.empty(M)
@@ -235,31 +242,47 @@ class FitRun:
 
     def iterate(self, it: int) -> Optional[float]:
         """One NIPALS inner iteration (tpls.py:80-107).  Returns |u_old - u|_2 (None on the first
-        pass of a component, where the reference compares against +inf)."""
+        pass of a component, where the reference compares against +inf).
+
+        The rank-1 extraction is launched with a squaring budget learnt from the previous iteration
+        (+3); its convergence flag comes back with the convergence norm in the single device->host
+        copy the iteration needs anyway, and in the rare case the budget was too small the tail of the
+        iteration is redone with the full budget (identically on every rank: the flag is a
+        deterministic function of the all-reduced Z)."""
         be, comm = self.eng.be, self.eng.comm
         self._executed += 1
         for b, blk in enumerate(self.blocks):
-            X2 = self.X2[b]
-            be.mode0_contract(X2, self.u, blk.has_miss, out=self.Zs[b])          # tpls.py:80-83
+            be.mode0_contract(self.X2[b], self.u, blk.has_miss, out=self.Zs[b])  # tpls.py:80-83
             comm.allreduce(self.Zs[b])
             if blk.has_miss:
                 be.colscale(self.Zs[b], blk.colcnt, self.n_total)                # missingvals.py:17-19
-            self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b])             # tpls.py:84-90
-            be.score(X2, blk.A, blk.B, self.wA[b], self.wB[b], blk.rowcnt if blk.has_miss else None, self.Ts[b])   # tpls.py:92-99
-        if self.coupled:
-            be.scores_mean(self.Ts, self.t)                                      # cmtf.py:120
-        else:
-            self.t.copy_(self.Ts[0])
-        qraw = be.gram_tn(self.Y, self.t).view(-1)                               # tpls.py:100
-        comm.allreduce(qraw)
-        self.q.copy_(qraw)
-        be.normalize(self.q)                                                     # tpls.py:101
-        du2 = be.rowdot(self.Y, self.q, self.u_new, self.u if it > 0 else None)  # tpls.py:102
+        while True:
+            for b, blk in enumerate(self.blocks):
+                self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b],
+                                info=self.status[1 + 2 * b: 3 + 2 * b], n_squarings=self.sq_budget[b])   # tpls.py:84-90
+                be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b],
+                         blk.rowcnt if blk.has_miss else None, self.Ts[b])        # tpls.py:92-99
+            if self.t.data_ptr() != self.Ts.data_ptr():
+                be.scores_mean(self.Ts, self.t)                                  # cmtf.py:120
+            be.gram_tn(self.Y, self.t, out=self.q)                               # tpls.py:100
+            comm.allreduce(self.q)
+            be.normalize(self.q)                                                 # tpls.py:101
+            be.rowdot(self.Y, self.q, self.u_new, self.u if it > 0 else None, du2=self.status[0:1])   # tpls.py:102
+            if it > 0:
+                comm.allreduce(self.status[0:1])
+            host = self.status.cpu().numpy()
+            retry = False
+            for b in range(len(self.blocks)):
+                conv, used = host[1 + 2 * b] > 0.5, int(host[2 + 2 * b])
+                if not conv and self.sq_budget[b] < self.sq_max:
+                    self.sq_budget[b] = self.sq_max
+                    retry = True
+                elif conv:
+                    self.sq_budget[b] = min(self.sq_max, used + 3)
+            if not retry:
+                break
         self.u, self.u_new = self.u_new, self.u
-        if it == 0:
-            return None
-        comm.allreduce(du2)
-        return math.sqrt(float(du2.item()))                                      # tpls.py:103
+        return None if it == 0 else math.sqrt(float(host[0]))                    # tpls.py:103
 
     def finish_component(self, a: int) -> None:
         be, comm = self.eng.be, self.eng.comm

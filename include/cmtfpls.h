@@ -71,13 +71,16 @@ int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_sa
 /* ---- K2 rank-1 extraction ----------------------------------------------------------------------
  * rank1: leading singular pair of the A x B matrix Z: what
  *   parafac(Z, 1, tol, init="svd", normalize_factors=True)[1]   (tpls.py:86-88, cmtf.py:100-102)
- * returns for a matrix Z.  wA = u1, wB = v1 (unit norm), sigma[0] = sigma_1; sign: the largest-|.|
- * entry of wB is positive, wA follows (sigma > 0).  Method: repeated squaring of the Gram matrix of
- * the smaller side (at most n_squarings, early exit when numerically rank one), then two exact
- * power steps with Z.  normalize: v /= ||v||_2, the vector case `Z / norm(Z)` (tpls.py:84,
- * cmtf.py:98) and `q /= norm(q)` (tpls.py:101); nrm (nullable) receives the norm. */
+ * returns for a matrix Z.  wA = u1, wB = v1 (unit norm), sigma[0] = sigma_1 (nullable); sign: the
+ * largest-|.| entry of wB is positive, wA follows (sigma > 0).  Method: repeated squaring of the Gram
+ * matrix of the smaller side (at most n_squarings launches, the ones after convergence return at
+ * once), then one exact pass y = M^T seed, x = M y with Z itself.  info (nullable, 2 doubles):
+ * info[0] = 1 if the squaring was seen to converge within n_squarings (else the caller should call
+ * again with a larger budget), info[1] = squarings actually computed (budget hint for the next call).
+ * normalize: v /= ||v||_2, the vector case `Z / norm(Z)` (tpls.py:84, cmtf.py:98) and
+ * `q /= norm(q)` (tpls.py:101); nrm (nullable) receives the norm. */
 size_t cmtfpls_rank1_workspace_bytes(int A, int B);
-int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma,
+int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
                       int n_squarings, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_normalize_f64(double* v, int64_t n, double* nrm, void* stream);
 

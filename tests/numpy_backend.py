@@ -49,7 +49,11 @@ class NumpyBackend:
         with np.errstate(all="ignore"):
             z[...] = np.where(c > 0, z / c * n_samples, 0.0)
 
-    def rank1(self, Z, A, B, wA, wB):
+    rank1_squarings = 30
+
+    def rank1(self, Z, A, B, wA, wB, info=None, n_squarings=None):
+        if info is not None:
+            info[0], info[1] = 1.0, 0.0
         U, S, Vt = np.linalg.svd(_np(Z).reshape(A, B), full_matrices=False)
         u, v = U[:, 0], Vt[0]
         if v[np.argmax(np.abs(v))] < 0:
@@ -83,18 +87,26 @@ class NumpyBackend:
         self.score(X2, A, B, wA, wB, rowcnt, out)
         return self.deflate(X2, A, B, out, wA, wB)
 
-    def gram_tn(self, A, B):
+    def gram_tn(self, A, B, out=None):
         if A.dim() == 1:
             A = A.unsqueeze(1)
         if B.dim() == 1:
             B = B.unsqueeze(1)
-        return (A.t() @ B).contiguous()
+        C = (A.t() @ B).contiguous()
+        if out is not None:
+            out.copy_(C.view(out.shape))
+            return out
+        return C
 
-    def rowdot(self, Y, q, u_out, u_old):
+    def rowdot(self, Y, q, u_out, u_old, du2=None):
         u = Y @ q
-        du2 = torch.tensor([float(((u_old - u) ** 2).sum())], dtype=torch.float64) if u_old is not None else None
+        if u_old is not None:
+            val = float(((u_old - u) ** 2).sum())
+            if du2 is None:
+                du2 = torch.zeros(1, dtype=torch.float64)
+            du2[0] = val
         u_out.copy_(u)
-        return du2
+        return du2 if u_old is not None else None
 
     def scores_mean(self, Ts, out):
         out.copy_(torch.from_numpy(np.average(_np(Ts), axis=0)))
