@@ -1,0 +1,84 @@
+"""Sample-mode sharding of the engine with world_size 2 over gloo on CPU (NumPy test backend).
+
+Each rank holds half of the rows of X and Y; the all-reduced quantities (Z, Y^T t, |du|^2, normal
+equations, norms, column statistics) must make the sharded fit equal to the single-process fit and
+to the oracle: same loadings, q, coef_, R2X, R2Y, iteration counts on both ranks, and the local rows
+of T / U.  Also covers the NaN-masked path, whose rescale uses GLOBAL observation counts.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, case, ret):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from cmtf_pls_amd import ctPLS, tPLS
+        from cmtf_pls_amd.engine import Comm
+        from numpy_backend import NumpyBackend
+
+        x, y, cp = O.import_synthetic((60, 8, 6), 3, 3, error=0.1, seed=21)
+        if case == "nan":
+            x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
+        rows = slice(rank * 30, (rank + 1) * 30)
+        if case == "coupled":
+            xm = cp.factors[0] @ np.random.default_rng(4).normal(size=(9, 3)).T
+            m = ctPLS(3, backend=NumpyBackend(), comm=Comm())
+            m.fit([x[rows], xm[rows]], y[rows])
+            fit = O.fit_ctpls([x, xm], y, 3)
+            T, loads = m.factor_T, m.Xs_factors[0][1:]
+            r2x = m.R2Xs[0]
+        else:
+            m = tPLS(3, backend=NumpyBackend(), comm=Comm())
+            m.fit(x[rows], y[rows])
+            fit = O.fit_tpls(x, y, 3)
+            T, loads = m.X_factors[0], m.X_factors[1:]
+            r2x = m.R2X
+        np.testing.assert_allclose(T, fit.T[rows], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(m.Y_factors[0], fit.U[rows], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(m.Y_factors[1], fit.Q, rtol=1e-6, atol=1e-8)
+        for got, want in zip(loads, fit.loadings[0]):
+            np.testing.assert_allclose(np.abs(got), np.abs(want), rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(m.coef_, fit.coef, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(r2x, fit.r2x[0], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
+        assert list(m.n_iter_) == list(fit.n_iter)
+        # transform of the local rows needs no communication
+        if case != "coupled":
+            np.testing.assert_allclose(m.transform(x[rows]), fit.T[rows], rtol=1e-6, atol=1e-8)
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc() + repr(e)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["plain", "nan", "coupled"])
+def test_world2_matches_oracle(case):
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
