@@ -187,8 +187,15 @@ def main():
     ms = timer.mean_ms("deflate")
     kern["deflate"] = {"ms": ms, "alg_GB": 2 * xbytes / 1e9, "GBps": 2 * xbytes / ms / 1e6}
     dom = "mode0_contract" if kern["mode0_contract"]["ms"] >= kern["score"]["ms"] else "score"
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # from separate rocprofv3 --pmc passes (not live)
+    if os.path.exists(pmc_file) and (I_total, J, K, world) == (65536, 128, 128, 1):
+        pmc = json.load(open(pmc_file))["kernels"]
+        key = {"mode0_contract": "contract_vec_kernel", "score": "score_kernel"}[dom]
+        if key in pmc:
+            traffic, traffic_src = pmc[key]["hbm_bytes_per_launch"], "profiles/pmc_traffic.json"
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": xbytes, "avg_launch_ms": kern[dom]["ms"]}
     del Xw, Yw, run
 

@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcmtfpls.so")
+# CMTFPLS_LIB overrides the path (used only by tools/tune_sweeps.sh to A/B kernel variants)
+LIB_PATH = os.environ.get("CMTFPLS_LIB") or os.path.join(_HERE, "lib", "libcmtfpls.so")
 
 _P = c_void_p
 
@@ -30,6 +31,9 @@ SIGNATURES = {
     "cmtfpls_rank1_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cmtfpls_rank1_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_normalize_f64": (c_int, [_P, c_int64, _P, _P]),
+    "cmtfpls_rank1_tensor_workspace_bytes": (c_size_t, [_P, c_int]),
+    "cmtfpls_rank1_tensor_f64": (c_int, [_P, _P, c_int, c_double, _P, c_int, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_kron_f64": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "cmtfpls_score_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "cmtfpls_score_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "cmtfpls_deflate_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),

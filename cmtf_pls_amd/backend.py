@@ -94,6 +94,20 @@ class HipBackend:
                                               int(n_squarings or self.rank1_squarings),
                                               _ptr(ws), ws.numel(), self._stream()), "rank1")
 
+    def rank1_tensor(self, Z: torch.Tensor, dims, tol: float, factors: torch.Tensor,
+                     info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None) -> None:
+        """Rank-1 CP factors of an order-3/4 cross-covariance tensor; factors: (n, ld) f64, row m = mode m."""
+        import ctypes
+        arr = (ctypes.c_int * len(dims))(*[int(d) for d in dims])
+        ws = self._workspace("rank1t", self.lib.cmtfpls_rank1_tensor_workspace_bytes(arr, len(dims)))
+        _lib.check(self.lib.cmtfpls_rank1_tensor_f64(_ptr(Z), arr, len(dims), float(tol), _ptr(factors), factors.stride(0), _ptr(info),
+                                                     int(n_squarings or self.rank1_squarings), _ptr(ws), ws.numel(), self._stream()),
+                   "rank1_tensor")
+
+    def kron(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        _lib.check(self.lib.cmtfpls_kron_f64(_ptr(a), a.numel(), _ptr(b), b.numel(), _ptr(out), self._stream()), "kron")
+        return out
+
     def normalize(self, v: torch.Tensor) -> None:
         _lib.check(self.lib.cmtfpls_normalize_f64(_ptr(v), v.numel(), None, self._stream()), "normalize")
 

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
 #pragma unroll
     for (int e = 0; e < V; ++e) { acc[g][e] = 0.0; cnt[g][e] = 0.0; }
   }
-  constexpr int RU = 4;
+  constexpr int RU = kUnroll;
   int64_t r = r0;
   for (; r + RU <= r1; r += RU) {
     VT x[RU][U];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
       uu[s] = (MODE == 2) ? 1.0 : u[r + s];
 #pragma unroll
       for (int g = 0; g < U; ++g)
-        if (ok[g]) x[s][g] = *reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V);
+        if (ok[g]) x[s][g] = ld_stream(reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V));
     }
 #pragma unroll
     for (int s = 0; s < RU; ++s)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
 #pragma unroll
     for (int g = 0; g < U; ++g)
       if (ok[g]) {
-        const VT x = *reinterpret_cast<const VT*>(X + r * P + cbase + (int64_t)g * kSweepThreads * V);
+        const VT x = ld_stream(reinterpret_cast<const VT*>(X + r * P + cbase + (int64_t)g * kSweepThreads * V));
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const T xv = x.e[e];
@@ -256,11 +256,11 @@ __global__ __launch_bounds__(kSweepThreads) void score_kernel(
     double acc = 0.0;
     KronWalk w = w0;
     int64_t c = c0;
-    constexpr int UN = 4;
+    constexpr int UN = kUnroll;
     for (; c + (UN - 1) * step < P; c += UN * step) {
       VT x[UN];
 #pragma unroll
-      for (int s = 0; s < UN; ++s) x[s] = *reinterpret_cast<const VT*>(xr + c + s * step);
+      for (int s = 0; s < UN; ++s) x[s] = ld_stream(reinterpret_cast<const VT*>(xr + c + s * step));
 #pragma unroll
       for (int s = 0; s < UN; ++s) {
         acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x[s], sB + w.k), acc);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kSweepThreads) void score_kernel(
       }
     }
     for (; c < P; c += step) {
-      const VT x = *reinterpret_cast<const VT*>(xr + c);
+      const VT x = ld_stream(reinterpret_cast<const VT*>(xr + c));
       acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x, sB + w.k), acc);
       w.next();
     }
@@ -303,11 +303,11 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
     const double ti = t[row];
     KronWalk w = w0;
     int64_t c = c0;
-    constexpr int UN = 4;
+    constexpr int UN = kUnroll;
     for (; c + (UN - 1) * step < P; c += UN * step) {
       VT x[UN];
 #pragma unroll
-      for (int s = 0; s < UN; ++s) x[s] = *reinterpret_cast<const VT*>(xr + c + s * step);
+      for (int s = 0; s < UN; ++s) x[s] = ld_stream(reinterpret_cast<const VT*>(xr + c + s * step));
 #pragma unroll
       for (int s = 0; s < UN; ++s) {
         const double tw = ti * sA[w.j];
@@ -318,12 +318,12 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
           const double d = (nv == nv) ? (double)nv : 0.0;   // NaN (missing) stays NaN, skipped in the norm
           ssq = fma(d, d, ssq);
         }
-        *reinterpret_cast<VT*>(xr + c + s * step) = x[s];
+        st_stream(reinterpret_cast<VT*>(xr + c + s * step), x[s]);
         w.next();
       }
     }
     for (; c < P; c += step) {
-      VT x = *reinterpret_cast<const VT*>(xr + c);
+      VT x = ld_stream(reinterpret_cast<const VT*>(xr + c));
       const double tw = ti * sA[w.j];
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
         const double d = (nv == nv) ? (double)nv : 0.0;
         ssq = fma(d, d, ssq);
       }
-      *reinterpret_cast<VT*>(xr + c) = x;
+      st_stream(reinterpret_cast<VT*>(xr + c), x);
       w.next();
     }
   }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kSweepThreads) void center_kernel(
     T* __restrict__ xr = X + row * P;
     double cnt = 0.0;
     for (int64_t c = (int64_t)lane * V; c < P; c += step) {
-      VT x = *reinterpret_cast<const VT*>(xr + c);
+      VT x = ld_stream(reinterpret_cast<const VT*>(xr + c));
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         const T nv = (T)((double)x.e[e] - mean[c + e]);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kSweepThreads) void center_kernel(
         const double d = obs ? (double)nv : 0.0;
         ssq = fma(d, d, ssq);
       }
-      *reinterpret_cast<VT*>(xr + c) = x;
+      st_stream(reinterpret_cast<VT*>(xr + c), x);
     }
     cnt = wave_sum(cnt);
     if (rowcnt && lane == 0) rowcnt[row] = cnt;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
     VT x[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n)
-      if (c0 + n * stride < P) x[n] = *reinterpret_cast<const VT*>(xr + c0 + n * stride);
+      if (c0 + n * stride < P) x[n] = ld_stream(reinterpret_cast<const VT*>(xr + c0 + n * stride));
     double acc = 0.0;
     {
       KronWalk w = w0;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
             const double d = (nv == nv) ? (double)nv : 0.0;
             ssq = fma(d, d, ssq);
           }
-          *reinterpret_cast<VT*>(xr + c0 + n * stride) = x[n];
+          st_stream(reinterpret_cast<VT*>(xr + c0 + n * stride), x[n]);
         }
         w.next();
         if (NV > 4) __builtin_amdgcn_sched_barrier(0);

@@ -117,16 +117,34 @@ class NipalsEngine:
                           colcnt=colcnt if has_miss else None, rowcnt=rowcnt, ssq0=float(ssq0.item()))
 
     def _rank1(self, blk: BlockState, Z: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
-               info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None) -> None:
-        """tpls.py:84-90: Z / norm(Z) for a vector, leading singular pair for a matrix."""
-        if len(blk.shape) > 3:
-            raise NotImplementedError("X blocks of order >= 4 (cross-covariance tensor of order >= 3) are not built yet")
-        if len(blk.shape) == 2:
+               info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None,
+               fac: Optional[torch.Tensor] = None, tol: float = 1e-8) -> None:
+        """tpls.py:84-90: Z / norm(Z) for a vector, leading singular pair for a matrix, rank-1 CP
+        (tensorly parafac restated) for a tensor; fills the factored loading (wA, wB)."""
+        order = len(blk.shape)
+        if order == 2:
             wB.copy_(Z)
             self.be.normalize(wB)
             wA.fill_(1.0)
-        else:
+        elif order == 3:
             self.be.rank1(Z, blk.A, blk.B, wA, wB, info=info, n_squarings=n_squarings)
+        else:
+            if order > 5:
+                raise NotImplementedError("X blocks of order > 5 are not supported")
+            dims = blk.shape[1:]
+            self.be.rank1_tensor(Z, dims, tol, fac, info=info, n_squarings=None)
+            wA.copy_(fac[0, : dims[0]])
+            self.kron_trailing([fac[m, : dims[m]] for m in range(1, len(dims))], wB)
+
+    def kron_trailing(self, vecs: List[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
+        """wB = kron(v_1, v_2, ...) of the trailing-mode loadings except the first (C order)."""
+        if len(vecs) == 1:
+            out.copy_(vecs[0])
+            return out
+        acc = vecs[0].contiguous()
+        for v in vecs[1:-1]:
+            acc = self.be.kron(acc, v.contiguous(), self.be.empty(acc.numel() * v.numel()))
+        return self.be.kron(acc, vecs[-1].contiguous(), out)
 
     # ------------------------------------------------------------------------------------
     def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool) -> "FitRun":
@@ -137,6 +155,7 @@ class NipalsEngine:
             coupled: bool, verbose: int = 0) -> FitState:
         """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy."""
         run = self.begin(Xs, Y, n_components, coupled)
+        run.tol = tol                                            # also handed to parafac (tpls.py:86)
         for a in range(n_components):
             run.start_component(a)
             for it in range(max_iter):                           # tpls.py:79
@@ -173,7 +192,7 @@ class NipalsEngine:
                     wbs.append(blk.loadings[0][:, a].contiguous())
                 else:
                     was.append(blk.loadings[0][:, a].contiguous())
-                    wbs.append(blk.loadings[1][:, a].contiguous())
+                    wbs.append(self.kron_trailing([L[:, a] for L in blk.loadings[1:]], be.empty(blk.B)))
             if nb == 1:
                 blk, X2 = state.blocks[0], Xs[0].view(I, -1)
                 if be.score_deflate(X2, blk.A, blk.B, was[0], wbs[0], rowcnts[0], t) is None:
@@ -222,6 +241,8 @@ class FitRun:
         self.wA = [be.empty(blk.A) for blk in self.blocks]
         self.wB = [be.empty(blk.B) for blk in self.blocks]
         self.Zs = [be.empty(blk.A * blk.B) for blk in self.blocks]
+        self.fac = [be.zeros(len(blk.shape) - 1, max(blk.shape[1:])) if len(blk.shape) > 3 else None for blk in self.blocks]
+        self.tol = 1e-8
         self.Ts = be.empty(len(self.blocks), I)
         # one block, no averaging: the score kernel writes t directly (no copy)
         self.t = self.Ts[0] if (len(self.blocks) == 1 and not coupled) else be.empty(I)
@@ -258,8 +279,8 @@ class FitRun:
                 be.colscale(self.Zs[b], blk.colcnt, self.n_total)                # missingvals.py:17-19
         while True:
             for b, blk in enumerate(self.blocks):
-                self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b],
-                                info=self.status[1 + 2 * b: 3 + 2 * b], n_squarings=self.sq_budget[b])   # tpls.py:84-90
+                self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b], info=self.status[1 + 2 * b: 3 + 2 * b],
+                                n_squarings=self.sq_budget[b], fac=self.fac[b], tol=self.tol)   # tpls.py:84-90
                 be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b],
                          blk.rowcnt if blk.has_miss else None, self.Ts[b])        # tpls.py:92-99
             if self.t.data_ptr() != self.Ts.data_ptr():
@@ -277,7 +298,7 @@ class FitRun:
                 if not conv and self.sq_budget[b] < self.sq_max:
                     self.sq_budget[b] = self.sq_max
                     retry = True
-                elif conv:
+                elif conv and len(self.blocks[b].shape) == 3:
                     self.sq_budget[b] = min(self.sq_max, used + 3)
             if not retry:
                 break
@@ -294,9 +315,12 @@ class FitRun:
         for b, blk in enumerate(self.blocks):
             if len(blk.shape) == 2:
                 blk.loadings[0][:, a].copy_(self.wB[b])
-            else:
+            elif len(blk.shape) == 3:
                 blk.loadings[0][:, a].copy_(self.wA[b])
                 blk.loadings[1][:, a].copy_(self.wB[b])
+            else:
+                for m, d in enumerate(blk.shape[1:]):
+                    blk.loadings[m][:, a].copy_(self.fac[b][m, :d])
             ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
         # inner regression: coef_[:, a] = lstsq(T, u) with columns > a still zero (tpls.py:110-112)
         Ta = self.T[:, : a + 1]

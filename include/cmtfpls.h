@@ -83,6 +83,16 @@ size_t cmtfpls_rank1_workspace_bytes(int A, int B);
 int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
                       int n_squarings, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_normalize_f64(double* v, int64_t n, double* nrm, void* stream);
+/* rank1_tensor: the same parafac call when Z is a TENSOR of order n = 3 or 4 (X of order 4 or 5,
+ * exercised by tests/test_cmtf.py:18-21, tests/test_tpls.py:132-155): leading-left-singular-vector
+ * init of every unfolding, ALS sweeps, stop when |d rec_error| < tol from the 2nd sweep on (<= 100
+ * sweeps), as tensorly 0.9.0 publishes it.  dims: HOST array of the n mode sizes (each <= 1024);
+ * factors: device (n x ld) row-major, row m = factor of mode m; info as for rank1 (info[1] = sweeps).
+ * kron: out[c] = a[c / nb] * b[c % nb] (builds wB of the factored loading from the trailing factors). */
+size_t cmtfpls_rank1_tensor_workspace_bytes(const int* dims, int n);
+int cmtfpls_rank1_tensor_f64(const double* Z, const int* dims, int n, double tol, double* factors, int ld,
+                             double* info, int n_squarings, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_kron_f64(const double* a, int na, const double* b, int nb, double* out, void* stream);
 
 /* ---- K3 score contraction: multi_mode_dot(X, [w...], range(1, X.ndim))  tpls.py:97-99 ---------
  * t[i] = sum_c X[i,c] * wA[c / B] * wB[c % B].

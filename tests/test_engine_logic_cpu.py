@@ -123,3 +123,33 @@ def test_no_cpu_fallback_in_product_path():
     x, y, _ = O.import_synthetic((10, 4, 3), 2, 2)
     with pytest.raises(_lib.CmtfplsError):
         tPLS(2).fit(x, y)                                      # no GPU here -> must fail loudly
+
+
+@pytest.mark.parametrize("shape", [(20, 8, 6, 4), (12, 5, 4, 3, 2)])
+def test_tpls_higher_order(shape):
+    """X of order 4 / 5 (tests/test_tpls.py:132-155 use order 4): rank-1 CP of a tensor Z."""
+    rng = np.random.default_rng(7)
+    X, Y = rng.random(shape), rng.random((shape[0], 5))
+    m = tPLS(4, backend=NumpyBackend())
+    m.fit(X, Y)
+    fit = O.fit_tpls(X, Y, 4)
+    np.testing.assert_allclose(m.X_factors[0], fit.T, rtol=1e-7, atol=1e-8)
+    for got, want in zip(m.X_factors[1:], fit.loadings[0]):
+        np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m.R2X, fit.r2x[0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-7, atol=1e-9)
+    order = rng.permutation(shape[0])
+    xs, ys = m.transform(X[order], Y[order])
+    assert np.allclose(xs, m.X_factors[0][order]) and np.allclose(ys, m.Y_factors[0][order])
+
+
+def test_ctpls_mixed_orders():
+    rng = np.random.default_rng(9)                              # tests/test_cmtf.py:18-29
+    Xs = [rng.random(d) for d in [(10, 9, 8, 7), (10, 8, 7), (10, 8)]]
+    Y = rng.random((10, 5))
+    m = ctPLS(4, backend=NumpyBackend())
+    m.fit(Xs, Y)
+    fit = O.fit_ctpls(Xs, Y, 4)
+    np.testing.assert_allclose(m.factor_T, fit.T, rtol=1e-6, atol=1e-8)
+    assert np.allclose(m.factor_T, m.transform(Xs))
+    np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)

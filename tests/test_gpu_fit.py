@@ -232,3 +232,49 @@ def test_medium_f32_against_oracle(api):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("shape,dtype,rtol", [((20, 8, 6, 4), "float64", 1e-6), ((12, 5, 4, 3, 2), "float64", 1e-6),
+                                              ((20, 8, 6, 4), "float32", 5e-5)])
+def test_tpls_higher_order(api, shape, dtype, rtol):
+    """X of order 4 and 5 (the shapes of tests/test_tpls.py:132-155, tests/test_missingvals.py:52)."""
+    rng = np.random.default_rng(7)
+    X, Y = rng.random(shape), rng.random((shape[0], 5))
+    if dtype == "float32":
+        X, Y = X.astype(np.float32).astype(np.float64), Y.astype(np.float32).astype(np.float64)
+    m = api.tPLS(4, dtype=dtype)
+    m.fit(X, Y)
+    fit = O.fit_tpls(X, Y, 4)
+    assert_allclose(m.X_factors[0], fit.T, rtol=rtol, atol=rtol * np.abs(fit.T).max())
+    for got, want in zip(m.X_factors[1:], fit.loadings[0]):
+        assert_allclose(got, want, rtol=rtol, atol=rtol)
+    assert_allclose(m.R2X, fit.r2x[0], rtol=rtol, atol=rtol)
+    assert_allclose(m.R2Y, fit.r2y, rtol=rtol, atol=rtol)
+    order = rng.permutation(shape[0])
+    xs, ys = m.transform(X[order], Y[order])                  # tests/test_tpls.py:145-155
+    assert np.allclose(xs, m.X_factors[0][order], rtol=10 * rtol, atol=10 * rtol)
+    assert np.allclose(ys, m.Y_factors[0][order], rtol=10 * rtol, atol=10 * rtol)
+
+
+def test_ctpls_mixed_orders(api):                             # tests/test_cmtf.py:18-29
+    rng = np.random.default_rng(9)
+    Xs = [rng.random(d) for d in [(10, 9, 8, 7, 6), (10, 9, 8, 7), (10, 9, 8)]]
+    Y = rng.random((10, 5))
+    m = api.ctPLS(6)
+    m.fit(Xs, Y)
+    fit = O.fit_ctpls(Xs, Y, 6)
+    assert_allclose(m.factor_T, fit.T, rtol=1e-5, atol=1e-6)
+    assert np.allclose(m.factor_T, m.transform(Xs))
+    assert np.all(np.diff(m.R2Y))
+    assert_allclose(m.R2Y, fit.r2y, rtol=1e-5, atol=1e-7)
+
+
+def test_miss_x_higher_order(api):                            # tests/test_missingvals.py:70-80
+    rng = np.random.default_rng(12)
+    X, Y = rng.random((10, 7, 6, 5)), rng.random((10, 4))
+    X[rng.random(X.shape) < 0.2] = np.nan
+    m = api.tPLS(7)
+    m.fit(X, Y)
+    assert np.all(np.diff(m.R2X) >= -1e-12) and np.all(np.diff(m.R2Y) >= -1e-12)
+    xs, ys = m.transform(X, Y)
+    assert np.allclose(m.X_factors[0], xs) and np.allclose(m.Y_factors[0], ys)

@@ -280,3 +280,31 @@ def test_full_size_properties_cfg2(be):
     t2 = be.score(X, A, B, wa, wb, None, be.empty(I))
     assert float(t2.abs().max()) < 1e-4 * float(t.abs().max())
     assert ssq0 > 0 and part.numel() == be.n_partials
+
+
+@pytest.mark.parametrize("dims", [(9, 8, 7), (5, 4, 3, 2), (38, 12, 10), (3, 70, 5)])
+def test_rank1_tensor_matches_oracle(be, dims):
+    """Order-3/4 cross-covariance tensor: same restatement of tensorly's parafac as the oracle
+    (value-level parity with tensorly itself is unpinned)."""
+    rng = np.random.default_rng(14)
+    Z = rng.normal(size=dims)
+    for v in [rng.normal(size=d) for d in dims][:1]:
+        pass
+    rank1 = rng.normal(size=dims[0])
+    for d in dims[1:]:
+        rank1 = np.multiply.outer(rank1, rng.normal(size=d))
+    Z = Z + 2.0 * rank1
+    fac = be.zeros(len(dims), max(dims))
+    info = be.zeros(2)
+    be.rank1_tensor(dev(Z.ravel()), dims, 1e-8, fac, info=info)
+    want = O.rank1_factors(Z, 1e-8)
+    got = host(fac)
+    for m, w in enumerate(want):
+        np.testing.assert_allclose(got[m, : dims[m]], w, rtol=1e-7, atol=1e-9)
+    assert host(info)[0] == 1.0
+
+
+def test_kron(be):
+    rng = np.random.default_rng(15)
+    a, b = rng.normal(size=7), rng.normal(size=13)
+    np.testing.assert_array_equal(host(be.kron(dev(a), dev(b), be.empty(91))), np.kron(a, b))

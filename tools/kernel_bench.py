@@ -30,6 +30,7 @@ def main():
     ap.add_argument("shape", nargs="*", type=int, default=[65536, 128, 128])
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--M", type=int, default=16)
+    ap.add_argument("--only", default="all")
     args = ap.parse_args()
     I, A, B = args.shape
     P = A * B
@@ -64,6 +65,8 @@ def main():
     rec("score masked", lambda: be.score(X, A, B, wa, wb, rowcnt, t), xbytes)
     rec("deflate (r+w)", lambda: be.deflate(X, A, B, tsmall, wa, wb), 2 * xbytes)
     rec("score_deflate fused (r+w)", lambda: be.score_deflate(X, A, B, wa, wb, None, t2), 2 * xbytes)
+    if args.only == "sweeps":
+        return
     rec("colstats", lambda: be.colstats(X), xbytes)
     rec("center (r+w)", lambda: be.center(X, torch.zeros(P, device='cuda:0', dtype=torch.float64), False), 2 * xbytes)
     wA, wB = be.empty(A), be.empty(B)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Build variant libraries of the sweep kernels (compile-time knobs) into cmtf_pls_amd/lib/variants/
+# Usage: tools/tune_sweeps.sh build   (here, cross-compile)   |   tools/tune_sweeps.sh run (GPU box)
+set -euo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+SRC="$ROOT/cmtf_pls_amd/csrc"
+OUT="$ROOT/cmtf_pls_amd/lib/variants"
+VARIANTS=("base:" "ntst:-DCMTFPLS_NT_STORE=1" "ntld:-DCMTFPLS_NT_LOAD=1" "ntboth:-DCMTFPLS_NT_LOAD=1 -DCMTFPLS_NT_STORE=1"
+          "b1024u8:-DCMTFPLS_SWEEP_BLOCKS=1024 -DCMTFPLS_UNROLL=8" "b4096:-DCMTFPLS_SWEEP_BLOCKS=4096" "u8:-DCMTFPLS_UNROLL=8" "u2:-DCMTFPLS_UNROLL=2")
+if [ "${1:-build}" = build ]; then
+  mkdir -p "$OUT"
+  for v in "${VARIANTS[@]}"; do
+    name="${v%%:*}"; flags="${v#*:}"
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags \
+        "$SRC/runtime.hip" "$SRC/sweeps.hip" "$SRC/small.hip" "$SRC/rank1.hip" "$SRC/rank1_tensor.hip" -o "$OUT/libcmtfpls_$name.so" ) &
+  done
+  wait
+  ls -la "$OUT"
+else
+  for v in "${VARIANTS[@]}"; do
+    name="${v%%:*}"
+    echo "=== variant $name"
+    CMTFPLS_LIB="$OUT/libcmtfpls_$name.so" python "$ROOT/tools/kernel_bench.py" --only sweeps 2>&1 | grep -v amdgpu.ids
+  done
+fi
