@@ -213,6 +213,27 @@ def main():
         fit_info = {"seconds": fit_s, "n_iter": list(st.n_iter), "iters_per_sec_in_fit": sum(st.n_iter) / fit_s,
                     "R2X_final": float(st.blocks[0].r2x[-1]), "R2Y_final": float(st.r2y[-1]), "tol": 1e-8, "max_iter": 100}
         del Xf, Yf
+        # the same fit through the cross-covariance form (algorithm="xcov": S = X^T Y on the f64 matrix
+        # cores, inner loop on S; exact re-association, one X read + one read/write per component)
+        Xf, Yf = X.clone(), Y.clone()
+        timer.records["xcov"] = []
+        be.xcov = timer._wrap("xcov", be.xcov)
+        timer.on = True
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        sx = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov")
+        torch.cuda.synchronize()
+        xs = time.perf_counter() - t1
+        timer.on = False
+        xms = timer.mean_ms("xcov")
+        fit_info["xcov"] = {"seconds": xs, "n_iter": list(sx.n_iter), "iters_per_sec_in_fit": sum(sx.n_iter) / xs,
+                            "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
+                            "max_abs_dT_vs_direct": float((sx.T - st.T).abs().max()),
+                            "xcov_kernel": {"ms": xms, "alg_GB": xbytes / 1e9, "GBps": xbytes / xms / 1e6,
+                                            "f64_mfma_TFLOPs": 2.0 * rows * J * K * M / xms / 1e9}}
+        del Xf, Yf
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

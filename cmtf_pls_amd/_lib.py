@@ -34,6 +34,10 @@ SIGNATURES = {
     "cmtfpls_rank1_tensor_workspace_bytes": (c_size_t, [_P, c_int]),
     "cmtfpls_rank1_tensor_f64": (c_int, [_P, _P, c_int, c_double, _P, c_int, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_kron_f64": (c_int, [_P, c_int, _P, c_int, _P, _P]),
+    "cmtfpls_xcov_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "cmtfpls_xcov_f32": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_xcov_f64": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_quadform_f64": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "cmtfpls_score_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "cmtfpls_score_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "cmtfpls_deflate_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),

@@ -111,6 +111,22 @@ class HipBackend:
     def normalize(self, v: torch.Tensor) -> None:
         _lib.check(self.lib.cmtfpls_normalize_f64(_ptr(v), v.numel(), None, self._stream()), "normalize")
 
+    # -- cross-covariance form (exact re-association of the loop, see include/cmtfpls.h) --------
+    def xcov(self, X2: torch.Tensor, Y: torch.Tensor, masked: bool, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """S (M, P) = Y^T X_(0) on the f64 matrix cores; None when M > 64 (caller uses the direct loop)."""
+        I, P = X2.shape
+        M = Y.shape[1]
+        if M > 64:
+            return None
+        ws = self._workspace("contract", self.lib.cmtfpls_xcov_workspace_bytes(I, P, M))
+        S = out if out is not None else self.empty(M, P)
+        _lib.check(self._fn("xcov", X2)(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
+        return S
+
+    def quadform(self, G: torch.Tensor, q: torch.Tensor, q_old: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        _lib.check(self.lib.cmtfpls_quadform_f64(_ptr(G), G.shape[0], _ptr(q), _ptr(q_old), _ptr(out), self._stream()), "quadform")
+        return out
+
     # -- K3: tpls.py:92-99 / missingvals.py:23-38 --------------------------------------------
     def score(self, X2, A, B, wA, wB, rowcnt, out) -> torch.Tensor:
         _lib.check(self._fn("score", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), self._stream()), "score")

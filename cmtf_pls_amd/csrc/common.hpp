@@ -43,6 +43,8 @@ struct VecOf {
 // 5.76 / 5.86 TB/s to 6.42 / 6.53 TB/s (contraction / score); nt stores +2 % on the deflation sweep.
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 template <int BYTES> struct NtRaw;
+typedef double nt_d4 __attribute__((ext_vector_type(4)));
+template <> struct NtRaw<32> { using type = nt_d4; };
 template <> struct NtRaw<16> { using type = nt_f4; };
 template <> struct NtRaw<8> { using type = double; };
 template <> struct NtRaw<4> { using type = float; };

@@ -1,0 +1,190 @@
+// Cross-covariance contraction  S[m, c] = sum_i Y[i, m] * X[i, c]   (S = X_(0)^T Y, M x P, f64)
+// on the matrix cores: v_mfma_f64_16x16x4_f64, X converted on load, f64 accumulation throughout.
+//
+// Why it exists: inside one component X and Y are fixed and u = Y q, so the
+// mode-0 contraction of every NIPALS iteration is Z = X x_0 u = sum_m q_m S_m and the Y update is
+// Y^T t = S_(0) (w_J (x) w_K): the whole inner loop of tpls.py:79-107 can run on S (1-17 MB) and X is
+// read once per component here instead of twice per iteration.  The result is the same arithmetic
+// re-associated; engine.py offers it as algorithm="xcov".
+//
+// Tile mapping (64-wide wavefront, one MFMA = 16 (m) x 16 (cols) x 4 (rows of X)):
+//   lane l: kq = l >> 4 (row of X inside the 4-row step), nn = l & 15.
+//   A operand  = Y[r + kq][16*mt + nn]                       (A[i = l&15][k = l>>4])
+//   the lane loads X[r + kq][cb + 4*nn .. 4*nn+3] as ONE 16-byte vector (a wave reads 4 rows x 256
+//   contiguous bytes per instruction) and feeds element e to MFMA e, whose output column nn is
+//   therefore X column cb + 4*nn + e:  B operand of MFMA e = X[r + kq][cb + 4*nn + e].
+//   D tile e, register g: S[16*mt + kq + 4*g][cb + 4*nn + e]  (f64 map: col = l&15, row = (l>>4) + 4*g)
+//   so each lane ends with 4 consecutive columns per (mt, g): 32-byte stores, 512 B per 16 lanes.
+// Rows are split over gridDim.y row blocks -> (row block, M, P) f64 partials, summed in fixed order.
+#include "common.hpp"
+
+namespace cmtfpls {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st);
+
+struct XcovPlan {
+  int col_tiles, row_blocks, rows_per_block;
+};
+
+static XcovPlan plan_xcov(int64_t I, int64_t P) {
+  XcovPlan p;
+  p.col_tiles = (int)((P + 255) / 256);                 // 4 waves x 64 columns per workgroup
+  int64_t want = (1024 + p.col_tiles - 1) / p.col_tiles;
+  if (want < 1) want = 1;
+  int64_t rpb = (I + want - 1) / want;
+  rpb = (rpb + 15) / 16 * 16;                            // multiple of the 4-row step x unroll
+  if (rpb < 64) rpb = 64;
+  p.rows_per_block = (int)rpb;
+  p.row_blocks = (int)((I + rpb - 1) / rpb);
+  if (p.row_blocks < 1) p.row_blocks = 1;
+  return p;
+}
+
+template <typename T, bool MASKED, bool VEC, int MT>
+__global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int64_t I, int64_t P,
+                                                  const double* __restrict__ Y, int ldy, int M,
+                                                  double* __restrict__ part, int rows_per_block) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kq = lane >> 4, nn = lane & 15;
+  const int64_t cb = ((int64_t)blockIdx.x * 4 + wv) * 64;
+  if (cb >= P) return;                                   // whole wavefront past the last column
+  const int64_t c = cb + 4 * nn;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  using XV = Pack<T, 4>;
+  d4_t acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[mt][e] = d4_t{0.0, 0.0, 0.0, 0.0};
+  bool mok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) mok[mt] = (mt * 16 + nn) < M;
+
+  // Every load is unconditional (clamped address) and masked afterwards: a guarded load makes hipcc
+  // branch around it and wait vmcnt(0) per load, which serialises the whole stream.  Two register
+  // stages: the loads of the next 16-row step are in flight while the MFMAs of the current one run.
+  constexpr int UN = 4;
+  const int64_t cc = (c < P) ? c : (VEC ? P - 4 : P - 1);
+  int ycol[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) ycol[mt] = mok[mt] ? mt * 16 + nn : M - 1;
+
+  auto load_stage = [&](XV (&x)[UN], double (&a)[UN][MT], int64_t r) {
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const int64_t row = r + 4 * s + kq;
+      const int64_t rowc = (row < r1) ? row : r1 - 1;
+      if (VEC) {
+        x[s] = ld_stream(reinterpret_cast<const XV*>(X + rowc * P + cc));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[s].e[e] = X[rowc * P + ((cc + e < P) ? cc + e : P - 1)];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[s][mt] = Y[rowc * ldy + ycol[mt]];
+    }
+  };
+  auto mma_stage = [&](const XV (&x)[UN], const double (&a)[UN][MT], int64_t r) {
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const bool rok = (r + 4 * s + kq) < r1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T xv = x[s].e[e];
+        if (MASKED) xv = (xv == xv) ? xv : (T)0;
+        const double b = (rok && c + e < P) ? (double)xv : 0.0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((rok && mok[mt]) ? a[s][mt] : 0.0, b, acc[mt][e], 0, 0, 0);
+      }
+    }
+  };
+
+  XV xa[UN], xb[UN];
+  double aa[UN][MT], ab[UN][MT];
+  load_stage(xa, aa, r0);
+  for (int64_t r = r0; r < r1; r += 8 * UN) {
+    load_stage(xb, ab, r + 4 * UN);       // rows past r1 are clamped on load and masked in the MFMAs
+    mma_stage(xa, aa, r);
+    load_stage(xa, aa, r + 8 * UN);
+    mma_stage(xb, ab, r + 4 * UN);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = mt * 16 + kq + 4 * g;
+      if (m < M) {
+        double* dst = part + ((int64_t)blockIdx.y * M + m) * P + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < P) dst[e] = acc[mt][e][g];
+      }
+    }
+}
+
+// du2 = (q - q_old)^T G (q - q_old):  |Y q - Y q_old|^2 with G = Y^T Y  (tpls.py:103 without
+// touching the I-long vectors)
+__global__ __launch_bounds__(256) void quadform_kernel(const double* __restrict__ G, int M, const double* __restrict__ q,
+                                                      const double* __restrict__ q_old, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int idx = threadIdx.x; idx < M * M; idx += 256) {
+    const int i = idx / M, j = idx - i * M;
+    s = fma((q[i] - q_old[i]) * G[idx], (q[j] - q_old[j]), s);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+template <typename T>
+static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
+                    void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!X || !Y || !S || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov: bad argument"); return CMTFPLS_EINVAL; }
+  if (M > 64) { set_error("xcov: more than 64 responses; use the direct algorithm"); return CMTFPLS_EUNSUPPORTED; }
+  const XcovPlan p = plan_xcov(I, P);
+  const size_t need = (size_t)p.row_blocks * M * P * sizeof(double);
+  if (!ws || ws_bytes < need) { set_error("xcov: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) == 0);
+  const int mt = (M + 15) / 16;                          // 1, 2, 3 -> 4, 4
+  double* part = static_cast<double*>(ws);
+  const dim3 grid(p.col_tiles, p.row_blocks), block(256);
+#define XL(MSK, VC, MTT) hipLaunchKernelGGL((xcov_kernel<T, MSK, VC, MTT>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block)
+#define XM(MSK, VC) do { if (mt == 1) XL(MSK, VC, 1); else if (mt == 2) XL(MSK, VC, 2); else XL(MSK, VC, 4); } while (0)
+  if (masked) { if (vec) XM(true, true); else XM(true, false); }
+  else        { if (vec) XM(false, true); else XM(false, false); }
+#undef XM
+#undef XL
+  launch_reduce_rows(part, p.row_blocks, (int64_t)M * P, S, st);
+  return check_launch("xcov");
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+
+size_t cmtfpls_xcov_workspace_bytes(int64_t I, int64_t P, int M) {
+  if (I <= 0 || P <= 0 || M <= 0) return 0;
+  const XcovPlan p = plan_xcov(I, P);
+  return (size_t)p.row_blocks * M * P * sizeof(double);
+}
+int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
+                     void* ws, size_t ws_bytes, void* stream) {
+  return run_xcov<float>(X, I, P, Y, ldy, M, S, masked, ws, ws_bytes, (hipStream_t)stream);
+}
+int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
+                     void* ws, size_t ws_bytes, void* stream) {
+  return run_xcov<double>(X, I, P, Y, ldy, M, S, masked, ws, ws_bytes, (hipStream_t)stream);
+}
+int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream) {
+  if (!G || !q || !q_old || !out || M <= 0) { set_error("quadform: bad argument"); return CMTFPLS_EINVAL; }
+  hipLaunchKernelGGL(quadform_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, M, q, q_old, out);
+  return check_launch("quadform");
+}
+
+}  // extern "C"

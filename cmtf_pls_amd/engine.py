@@ -147,14 +147,17 @@ class NipalsEngine:
         return self.be.kron(acc, vecs[-1].contiguous(), out)
 
     # ------------------------------------------------------------------------------------
-    def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool) -> "FitRun":
+    def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool,
+              algorithm: str = "direct") -> "FitRun":
         """Preprocess (centre in place) and allocate the per-fit buffers; see FitRun."""
-        return FitRun(self, Xs, Y, n_components, coupled)
+        return FitRun(self, Xs, Y, n_components, coupled, algorithm)
 
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
-            coupled: bool, verbose: int = 0) -> FitState:
-        """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy."""
-        run = self.begin(Xs, Y, n_components, coupled)
+            coupled: bool, verbose: int = 0, algorithm: str = "direct") -> FitState:
+        """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy.
+        algorithm: "direct" = the reference's loop (two X reads per iteration); "xcov" = the same
+        iteration re-associated through S = X_(0)^T Y (one X read + one read/write per component)."""
+        run = self.begin(Xs, Y, n_components, coupled, algorithm)
         run.tol = tol                                            # also handed to parafac (tpls.py:86)
         for a in range(n_components):
             run.start_component(a)
@@ -212,8 +215,14 @@ class FitRun:
     """One fit in flight: the state between NIPALS iterations.  ``fit`` drives it; bench.py drives
     ``iterate`` directly so that the timed step IS the product's iteration."""
 
-    def __init__(self, eng: NipalsEngine, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool):
+    def __init__(self, eng: NipalsEngine, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool,
+                 algorithm: str = "direct"):
         be, comm = eng.be, eng.comm
+        if algorithm not in ("direct", "xcov"):
+            raise ValueError("algorithm must be 'direct' or 'xcov'")
+        if algorithm == "xcov" and Y.shape[1] > 64:
+            algorithm = "direct"                                  # S = X^T Y is built for M <= 64 responses
+        self.algorithm = algorithm
         self.eng, self.Xs, self.Y, self.R, self.coupled = eng, Xs, Y, n_components, coupled
         R = n_components
         I, M = Y.shape
@@ -256,10 +265,75 @@ class FitRun:
         self.q = be.empty(M)
         self.n_iter: List[int] = []
         self._executed = 0
+        if algorithm == "xcov":
+            nb = len(self.blocks)
+            self.S = [be.empty(M, blk.A * blk.B) for blk in self.blocks]
+            # masked blocks: Y^T t needs the per-row rescale P / n_obs(i) of miss_mmodedot folded into Y
+            self.S2 = [be.empty(M, blk.A * blk.B) if blk.has_miss else None for blk in self.blocks]
+            self.rowscale = [(float(blk.A * blk.B) / blk.rowcnt) if blk.has_miss else None for blk in self.blocks]
+            self.Yw = be.empty(I, M) if any(blk.has_miss for blk in self.blocks) else None
+            self.Gy = be.empty(M, M)
+            self.Tq = be.empty(nb, M)
+            self.qc = be.empty(M)
+            self.qn = self.Tq[0] if (nb == 1 and not coupled) else be.empty(M)
 
     def start_component(self, a: int) -> None:
-        self.u.copy_(self.Y[:, 0])                                # tpls.py:78
         self._executed = 0
+        if self.algorithm == "direct":
+            self.u.copy_(self.Y[:, 0])                            # tpls.py:78
+            return
+        be, comm = self.eng.be, self.eng.comm
+        for b, blk in enumerate(self.blocks):
+            be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b])
+            comm.allreduce(self.S[b])
+            if blk.has_miss:
+                torch.mul(self.Y, self.rowscale[b][:, None], out=self.Yw)
+                be.xcov(self.X2[b], self.Yw, True, out=self.S2[b])
+                comm.allreduce(self.S2[b])
+        be.gram_tn(self.Y, self.Y, out=self.Gy)
+        comm.allreduce(self.Gy)
+        self.qc.zero_()
+        self.qc[0] = 1.0                                          # u_0 = Y[:, 0] = Y e_0   (tpls.py:78)
+
+    def _iterate_xcov(self, it: int) -> Optional[float]:
+        """The same iteration with X x_0 u = sum_m q_m S_m and Y^T t = S_(0) kron(wA, wB): only S is
+        touched (no X read, no communication: S is already global).  |u_old - u|^2 = dq^T (Y^T Y) dq."""
+        be = self.eng.be
+        self._executed += 1
+        for b, blk in enumerate(self.blocks):
+            be.mode0_contract(self.S[b], self.qc, False, out=self.Zs[b])         # tpls.py:80-83
+            if blk.has_miss:
+                be.colscale(self.Zs[b], blk.colcnt, self.n_total)                # missingvals.py:17-19
+        while True:
+            for b, blk in enumerate(self.blocks):
+                self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b], info=self.status[1 + 2 * b: 3 + 2 * b],
+                                n_squarings=self.sq_budget[b], fac=self.fac[b], tol=self.tol)   # tpls.py:84-90
+                be.score(self.S2[b] if blk.has_miss else self.S[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Tq[b])
+            if self.qn.data_ptr() != self.Tq.data_ptr():
+                be.scores_mean(self.Tq, self.qn)                                 # cmtf.py:120 (linear in t)
+            be.normalize(self.qn)                                                # tpls.py:100-101
+            if it > 0:
+                be.quadform(self.Gy, self.qn, self.qc, self.status[0:1])         # tpls.py:102-103
+            host = self.status.cpu().numpy()
+            if not self._update_budgets(host):
+                break
+        if self.qn.data_ptr() == self.Tq.data_ptr():
+            self.qc.copy_(self.qn)
+        else:
+            self.qc, self.qn = self.qn, self.qc
+        return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))
+
+    def _update_budgets(self, host) -> bool:
+        """Adapt the squaring budget of every order-3 block; True if the iteration tail must be redone."""
+        retry = False
+        for b in range(len(self.blocks)):
+            conv, used = host[1 + 2 * b] > 0.5, int(host[2 + 2 * b])
+            if not conv and self.sq_budget[b] < self.sq_max:
+                self.sq_budget[b] = self.sq_max
+                retry = True
+            elif conv and len(self.blocks[b].shape) == 3:
+                self.sq_budget[b] = min(self.sq_max, used + 3)
+        return retry
 
     def iterate(self, it: int) -> Optional[float]:
         """One NIPALS inner iteration (tpls.py:80-107).  Returns |u_old - u|_2 (None on the first
@@ -270,6 +344,8 @@ class FitRun:
         copy the iteration needs anyway, and in the rare case the budget was too small the tail of the
         iteration is redone with the full budget (identically on every rank: the flag is a
         deterministic function of the all-reduced Z)."""
+        if self.algorithm == "xcov":
+            return self._iterate_xcov(it)
         be, comm = self.eng.be, self.eng.comm
         self._executed += 1
         for b, blk in enumerate(self.blocks):
@@ -292,15 +368,7 @@ class FitRun:
             if it > 0:
                 comm.allreduce(self.status[0:1])
             host = self.status.cpu().numpy()
-            retry = False
-            for b in range(len(self.blocks)):
-                conv, used = host[1 + 2 * b] > 0.5, int(host[2 + 2 * b])
-                if not conv and self.sq_budget[b] < self.sq_max:
-                    self.sq_budget[b] = self.sq_max
-                    retry = True
-                elif conv and len(self.blocks[b].shape) == 3:
-                    self.sq_budget[b] = min(self.sq_max, used + 3)
-            if not retry:
+            if not self._update_budgets(host):
                 break
         self.u, self.u_new = self.u_new, self.u
         return None if it == 0 else math.sqrt(float(host[0]))                    # tpls.py:103
@@ -308,10 +376,29 @@ class FitRun:
     def finish_component(self, a: int) -> None:
         be, comm = self.eng.be, self.eng.comm
         self.n_iter.append(self._executed)
+        ssqs = []
+        if self.algorithm == "xcov":
+            # the final score (tpls.py:92-99 with the converged loadings) and the deflation (tpls.py:109)
+            # are the only other passes over X: fused into one read + one write when there is one block
+            self.q = self.qc
+            if len(self.blocks) == 1:
+                blk = self.blocks[0]
+                rc = blk.rowcnt if blk.has_miss else None
+                s0 = be.score_deflate(self.X2[0], blk.A, blk.B, self.wA[0], self.wB[0], rc, self.t)
+                if s0 is None:
+                    be.score(self.X2[0], blk.A, blk.B, self.wA[0], self.wB[0], rc, self.t)
+                    s0 = be.deflate(self.X2[0], blk.A, blk.B, self.t, self.wA[0], self.wB[0])
+                ssqs.append(s0)
+            else:
+                for b, blk in enumerate(self.blocks):
+                    be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], blk.rowcnt if blk.has_miss else None, self.Ts[b])
+                be.scores_mean(self.Ts, self.t)
+                for b, blk in enumerate(self.blocks):
+                    ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))
+            be.rowdot(self.Y, self.q, self.u, None)                              # u = Y q (tpls.py:102)
         self.T[:, a].copy_(self.t)
         self.U[:, a].copy_(self.u)
         self.Q[:, a].copy_(self.q)
-        ssqs = []
         for b, blk in enumerate(self.blocks):
             if len(blk.shape) == 2:
                 blk.loadings[0][:, a].copy_(self.wB[b])
@@ -321,7 +408,8 @@ class FitRun:
             else:
                 for m, d in enumerate(blk.shape[1:]):
                     blk.loadings[m][:, a].copy_(self.fac[b][m, :d])
-            ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
+            if self.algorithm == "direct":
+                ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
         # inner regression: coef_[:, a] = lstsq(T, u) with columns > a still zero (tpls.py:110-112)
         Ta = self.T[:, : a + 1]
         G = be.gram_tn(Ta, Ta)

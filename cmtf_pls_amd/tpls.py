@@ -4,7 +4,9 @@
 Same constructor, ``fit / predict / transform / X_reconstructed / copy``, Mapping protocol
 (``[0], [1], [2]`` -> X_factors, Y_factors, coef_) and fitted attributes; NumPy in, NumPy out.
 Opt-in extras (defaults reproduce the reference): ``dtype`` (storage type of X on the GPU:
-"float32" | "float64" | None = follow the input), ``device``, ``comm`` (sample-mode sharding: each
+"float32" | "float64" | None = follow the input), ``algorithm`` ("direct" = the reference's loop,
+"xcov" = the same iteration through the cross-covariance S = X_(0)^T Y, one X read per component),
+``device``, ``comm`` (sample-mode sharding: each
 rank passes its own rows), ``n_iter_`` (inner iterations executed per component) and
 ``original_X / original_Y`` (which the reference's validate.get_q2y reads, validate.py:18-21).
 """
@@ -40,9 +42,11 @@ def to_device_copy(X, dtype: torch.dtype, device) -> torch.Tensor:
 
 
 class _EstimatorBase(Mapping):
-    def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None):
+    def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None,
+                 algorithm: str = "direct"):
         super().__init__()
         self.n_components = n_components
+        self._algorithm = algorithm
         self._dtype = dtype
         self._device = device
         self._comm = comm
@@ -111,7 +115,7 @@ class tPLS(_EstimatorBase):
         self.Y_shape = tuple(Y2.shape)
         Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev)
         Yd = to_device_copy(Y2, torch.float64, dev)
-        st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose)
+        st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose, algorithm=self._algorithm)
         del Xd
         blk = st.blocks[0]
         self._state = st

@@ -94,6 +94,20 @@ int cmtfpls_rank1_tensor_f64(const double* Z, const int* dims, int n, double tol
                              double* info, int n_squarings, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_kron_f64(const double* a, int na, const double* b, int nb, double* out, void* stream);
 
+/* ---- cross-covariance contraction (not a reference call site: an exact re-association of the loop)
+ * xcov: S (M x P, row-major f64) = Y^T X_(0), i.e. S[m, c] = sum_i Y[i*ldy + m] * X[i, c], on the
+ * f64 matrix cores (v_mfma_f64_16x16x4_f64), one read of X.  Inside one component u = Y q, hence
+ * np.einsum(X, u) = sum_m q_m S[m] (tpls.py:83) and Y.T @ t = S_(0) kron(wA, wB) (tpls.py:100): the
+ * inner loop of tpls.py:79-107 can then run on S alone with mode0_contract_f64 / rank1 / score_f64
+ * applied to S.  masked != 0: NaN entries of X contribute 0.  M <= 64.
+ * quadform: out[0] = (q - q_old)^T G (q - q_old) = |Y q - Y q_old|^2 for G = Y^T Y (tpls.py:103). */
+size_t cmtfpls_xcov_workspace_bytes(int64_t I, int64_t P, int M);
+int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
+                     int masked, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
+                     int masked, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream);
+
 /* ---- K3 score contraction: multi_mode_dot(X, [w...], range(1, X.ndim))  tpls.py:97-99 ---------
  * t[i] = sum_c X[i,c] * wA[c / B] * wB[c % B].
  * rowcnt != NULL selects the masked form miss_mmodedot (missingvals.py:23-38): NaN entries

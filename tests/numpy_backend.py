@@ -44,6 +44,21 @@ class NumpyBackend:
             return out
         return z
 
+    def xcov(self, X2, Y, masked, out=None):
+        x = _np(X2).astype(np.float64)
+        if masked:
+            x = np.where(np.isnan(x), 0.0, x)
+        S = torch.from_numpy(_np(Y).T @ x)
+        if out is not None:
+            out.copy_(S)
+            return out
+        return S
+
+    def quadform(self, G, q, q_old, out):
+        d = q - q_old
+        out[0] = float(d @ G @ d)
+        return out
+
     def colscale(self, Z, colcnt, n_samples):
         z, c = _np(Z), _np(colcnt)
         with np.errstate(all="ignore"):

@@ -153,3 +153,35 @@ def test_ctpls_mixed_orders():
     np.testing.assert_allclose(m.factor_T, fit.T, rtol=1e-6, atol=1e-8)
     assert np.allclose(m.factor_T, m.transform(Xs))
     np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["plain", "nan", "matrix", "coupled"])
+def test_xcov_algorithm_equals_direct(case):
+    """algorithm="xcov" (inner loop on S = X^T Y) is the same iteration re-associated: identical
+    iteration counts and factors to rounding, for plain / NaN / matrix-X / coupled fits."""
+    rng = np.random.default_rng(31)
+    x, y, cp = O.import_synthetic((80, 9, 8), 5, 3, error=0.2, seed=8)
+    if case == "nan":
+        x[rng.random(x.shape) < 0.25] = np.nan
+    if case == "matrix":
+        x = x.reshape(80, 72)
+    if case == "coupled":
+        xm = cp.factors[0] @ rng.normal(size=(11, 3)).T + 0.1 * rng.normal(size=(80, 11))
+        a, b = ctPLS(3, backend=NumpyBackend()), ctPLS(3, backend=NumpyBackend(), algorithm="xcov")
+        a.fit([x, xm], y)
+        b.fit([x, xm], y)
+        Ta, Tb = a.factor_T, b.factor_T
+        r2a, r2b = a.R2Xs[0], b.R2Xs[0]
+    else:
+        a, b = tPLS(3, backend=NumpyBackend()), tPLS(3, backend=NumpyBackend(), algorithm="xcov")
+        a.fit(x, y)
+        b.fit(x, y)
+        Ta, Tb = a.X_factors[0], b.X_factors[0]
+        r2a, r2b = a.R2X, b.R2X
+    assert a.n_iter_ == b.n_iter_
+    np.testing.assert_allclose(Tb, Ta, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(b.Y_factors[0], a.Y_factors[0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(b.Y_factors[1], a.Y_factors[1], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(b.coef_, a.coef_, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(r2b, r2a, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(b.R2Y, a.R2Y, rtol=1e-9, atol=1e-11)

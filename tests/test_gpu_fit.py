@@ -278,3 +278,42 @@ def test_miss_x_higher_order(api):                            # tests/test_missi
     assert np.all(np.diff(m.R2X) >= -1e-12) and np.all(np.diff(m.R2Y) >= -1e-12)
     xs, ys = m.transform(X, Y)
     assert np.allclose(m.X_factors[0], xs) and np.allclose(m.Y_factors[0], ys)
+
+
+@pytest.mark.parametrize("case", ["plain", "nan", "matrix", "coupled", "f32"])
+def test_xcov_algorithm_on_gpu(api, case):
+    """algorithm="xcov": inner loop on S = X^T Y (f64 MFMA).  Same iteration counts and factors as the
+    direct loop and as the oracle."""
+    rng = np.random.default_rng(31)
+    x, y, cp = O.import_synthetic((300, 12, 8), 5, 3, error=0.2, seed=8)
+    dtype, rtol = ("float32", 2e-5) if case == "f32" else ("float64", 1e-7)
+    if case == "f32":
+        x, y = x.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64)
+    if case == "nan":
+        x[rng.random(x.shape) < 0.25] = np.nan
+    if case == "matrix":
+        x = x.reshape(300, 96)
+    if case == "coupled":
+        xm = cp.factors[0] @ rng.normal(size=(11, 3)).T + 0.1 * rng.normal(size=(300, 11))
+        m, d = api.ctPLS(3, algorithm="xcov"), api.ctPLS(3)
+        m.fit([x, xm], y)
+        d.fit([x, xm], y)
+        fit = O.fit_ctpls([x, xm], y, 3)
+        check_against_oracle(m, fit, rtol, block=0)
+        check_against_oracle(m, fit, rtol, block=1)
+        assert_allclose(m.R2Xs[1], fit.r2x[1], rtol=rtol, atol=rtol)
+        assert_allclose(m.factor_T, d.factor_T, rtol=1e-9, atol=1e-9)
+    else:
+        m, d = api.tPLS(3, dtype=dtype, algorithm="xcov"), api.tPLS(3, dtype=dtype)
+        m.fit(x, y)
+        d.fit(x, y)
+        fit = O.fit_tpls(x, y, 3)
+        if case == "matrix":
+            assert_allclose(m.X_factors[0], fit.T, rtol=rtol, atol=rtol * np.abs(fit.T).max())
+            assert_allclose(m.X_factors[1], fit.loadings[0][0], rtol=rtol, atol=rtol)
+            assert m.n_iter_ == list(fit.n_iter)
+        else:
+            check_against_oracle(m, fit, rtol, exact_iters=(case != "f32"))
+        assert_allclose(m.R2X, fit.r2x[0], rtol=rtol, atol=rtol)
+        assert_allclose(m.X_factors[0], d.X_factors[0], rtol=rtol, atol=rtol * np.abs(fit.T).max())
+        assert_allclose(m.transform(x), m.X_factors[0], rtol=10 * rtol, atol=10 * rtol * np.abs(fit.T).max())

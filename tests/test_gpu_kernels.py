@@ -308,3 +308,40 @@ def test_kron(be):
     rng = np.random.default_rng(15)
     a, b = rng.normal(size=7), rng.normal(size=13)
     np.testing.assert_array_equal(host(be.kron(dev(a), dev(b), be.empty(91))), np.kron(a, b))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape,M", [((37, 10, 8), 4), ((100, 38, 65), 3), ((64, 1, 20), 16), ((300, 16, 16), 17),
+                                     ((130, 128, 128), 16), ((257, 24, 12), 33), ((70, 8, 8), 64), ((1000, 16, 16), 16)])
+def test_xcov_mfma(be, shape, M, dt, masked):
+    """S = Y^T X_(0) on the f64 matrix cores against NumPy float64 (operand layout of
+    v_mfma_f64_16x16x4_f64 checked with asymmetric random data, every M-tile count, ragged rows/cols)."""
+    I = shape[0]
+    x = make_x(shape, dt, nan_frac=0.3 if masked else 0.0, seed=16)
+    y = np.random.default_rng(17).normal(size=(I, M))
+    S = be.xcov(dev(x, TDT[dt]), dev(y), masked)
+    want = y.T @ (np.nan_to_num(x) if masked else x)
+    np.testing.assert_allclose(host(S), want, rtol=1e-11, atol=1e-10)
+
+
+def test_xcov_identities_and_quadform(be):
+    """The two identities the xcov loop rests on: einsum(X, Y q) == sum_m q_m S_m and
+    Y^T (X w) == S_(0) w; and the quadratic form |Y q - Y q_old|^2."""
+    rng = np.random.default_rng(18)
+    I, A, B, M = 500, 12, 8, 6
+    x, y, q = rng.normal(size=(I, A * B)), rng.normal(size=(I, M)), rng.normal(size=M)
+    wa, wb = rng.normal(size=A), rng.normal(size=B)
+    X, Y = dev(x), dev(y)
+    S = be.xcov(X, Y, False)
+    Z_direct = be.mode0_contract(X, dev(y @ q), False).clone()
+    Z_xcov = be.mode0_contract(S, dev(q), False)
+    np.testing.assert_allclose(host(Z_xcov), host(Z_direct), rtol=1e-10, atol=1e-9)
+    t = be.score(X, A, B, dev(wa), dev(wb), None, be.empty(I))
+    q_direct = host(be.gram_tn(Y, t)).ravel()
+    q_xcov = host(be.score(S, A, B, dev(wa), dev(wb), None, be.empty(M)))
+    np.testing.assert_allclose(q_xcov, q_direct, rtol=1e-10, atol=1e-9)
+    q2 = rng.normal(size=M)
+    G = be.gram_tn(Y, Y)
+    out = be.quadform(G, dev(q), dev(q2), be.empty(1))
+    np.testing.assert_allclose(host(out)[0], np.sum((y @ q - y @ q2) ** 2), rtol=1e-11)

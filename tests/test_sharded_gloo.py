@@ -50,7 +50,7 @@ def _worker(rank, world, port, case, ret):
             T, loads = m.factor_T, m.Xs_factors[0][1:]
             r2x = m.R2Xs[0]
         else:
-            m = tPLS(3, backend=NumpyBackend(), comm=Comm())
+            m = tPLS(3, backend=NumpyBackend(), comm=Comm(), algorithm="xcov" if case == "xcov" else "direct")
             m.fit(x[rows], y[rows])
             fit = O.fit_tpls(x, y, 3)
             T, loads = m.X_factors[0], m.X_factors[1:]
@@ -75,7 +75,7 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["plain", "nan", "coupled"])
+@pytest.mark.parametrize("case", ["plain", "nan", "coupled", "xcov"])
 def test_world2_matches_oracle(case):
     world = 2
     with mp.Manager() as mgr:
