@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-fit", action="store_true", help="skip the sec-to-fit leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=2048)
+    ap.add_argument("--graphs", type=int, default=1, help="replay the iteration's launch sequence as a HIP graph (0 = eager)")
     return ap.parse_args()
 
 
@@ -147,26 +148,47 @@ def main():
     Xw, Yw = X.clone(), Y.clone()
     run = eng.begin([Xw], Yw, R, coupled=False)
     run.start_component(0)
-    for it in range(args.warmup):
-        run.iterate(it)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timer.on = True
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        run.iterate(args.warmup + it + 1)          # it > 0: convergence norm computed and read back
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timer.on = False
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    state = {"it": 0}
+
+    def timed(steps, events):
+        """barrier + sync, `steps` product iterations, sync + barrier; max over ranks (seconds)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer.on = events
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run.iterate(state["it"])               # it > 0 after warm-up: convergence norm computed and read back
+            state["it"] += 1
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timer.on = False
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    # (1) eager pass with HIP events bracketing every kernel launch (roofline figures come from here;
+    #     events cannot bracket kernels inside a graph replay)
+    for _ in range(args.warmup):
+        run.iterate(state["it"])
+        state["it"] += 1
+    eager_elapsed = timed(args.steps, events=True)
+    elapsed = eager_elapsed
+    # (2) the same K iterations with the launch sequence replayed as a HIP graph (the headline when
+    #     capture works: identical kernels, ~1 host call per iteration instead of ~20 launches)
+    if args.graphs:
+        run.use_graphs = True
+        for _ in range(max(args.warmup, 4)):       # captures both u-buffer parities
+            run.iterate(state["it"])
+            state["it"] += 1
+        if run.use_graphs:
+            elapsed = timed(args.steps, events=False)
+    graphs_used, graph_error = run.use_graphs, run._graph_error
     run.finish_component(0)                        # exercises the deflation sweep once (timed below by events)
 
     es = X.element_size()
@@ -248,7 +270,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: tPLS direct NIPALS iteration, X {I_total}x{J}x{K} f32 "
                                    f"(f64 accumulation), Y {I_total}x{M}, R={R}, noise {args.noise}",
                        "rows_per_gpu": rows, "parallelism": f"sample-mode shard x{world}" if world > 1 else "single GPU",
-                       "x_reads_per_step": 2},
+                       "x_reads_per_step": 2, "hip_graphs": bool(graphs_used), "graph_error": graph_error,
+                       "eager_ms_per_step": eager_elapsed / args.steps * 1e3},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "fit": fit_info,
         }
         print(json.dumps(out), flush=True)

@@ -265,6 +265,13 @@ class FitRun:
         self.q = be.empty(M)
         self.n_iter: List[int] = []
         self._executed = 0
+        self._parity = 0
+        self.use_graphs = False
+        self._graphs = {}
+        self._graph_error = None
+        if algorithm == "direct" and comm.world > 1:
+            self.Gy = be.empty(M, M)
+            self.q_prev = be.zeros(M)
         if algorithm == "xcov":
             nb = len(self.blocks)
             self.S = [be.empty(M, blk.A * blk.B) for blk in self.blocks]
@@ -279,10 +286,14 @@ class FitRun:
 
     def start_component(self, a: int) -> None:
         self._executed = 0
+        be, comm = self.eng.be, self.eng.comm
         if self.algorithm == "direct":
             self.u.copy_(self.Y[:, 0])                            # tpls.py:78
+            self._parity = 0
+            if comm.world > 1:
+                be.gram_tn(self.Y, self.Y, out=self.Gy)
+                comm.allreduce(self.Gy)
             return
-        be, comm = self.eng.be, self.eng.comm
         for b, blk in enumerate(self.blocks):
             be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b])
             comm.allreduce(self.S[b])
@@ -332,8 +343,31 @@ class FitRun:
                 self.sq_budget[b] = self.sq_max
                 retry = True
             elif conv and len(self.blocks[b].shape) == 3:
-                self.sq_budget[b] = min(self.sq_max, used + 3)
+                # hysteresis keeps the launch sequence (and a captured graph of it) stable
+                if used + 2 > self.sq_budget[b] or used + 6 < self.sq_budget[b]:
+                    self.sq_budget[b] = min(self.sq_max, used + 3)
         return retry
+
+    def _run(self, key, fn) -> None:
+        """Run one launch sequence; with use_graphs it is captured once per key into a HIP graph
+        (torch.cuda.CUDAGraph on the launch stream) and replayed afterwards: one host call instead of
+        ~20 kernel launches, which is what bounds a strongly-scaled iteration."""
+        if not self.use_graphs:
+            fn()
+            return
+        g = self._graphs.get(key)
+        if g is not None:
+            g.replay()
+            return
+        fn()                                   # eager: does this call's work and sizes every workspace
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[key] = g
+        except Exception as e:                 # capture unsupported in this context: stay eager
+            self.use_graphs = False
+            self._graph_error = repr(e)
 
     def iterate(self, it: int) -> Optional[float]:
         """One NIPALS inner iteration (tpls.py:80-107).  Returns |u_old - u|_2 (None on the first
@@ -348,12 +382,20 @@ class FitRun:
             return self._iterate_xcov(it)
         be, comm = self.eng.be, self.eng.comm
         self._executed += 1
-        for b, blk in enumerate(self.blocks):
-            be.mode0_contract(self.X2[b], self.u, blk.has_miss, out=self.Zs[b])  # tpls.py:80-83
-            comm.allreduce(self.Zs[b])
-            if blk.has_miss:
-                be.colscale(self.Zs[b], blk.colcnt, self.n_total)                # missingvals.py:17-19
-        while True:
+        sharded = comm.world > 1
+        par = self._parity                       # which of the two u buffers holds the current u
+        u, u_new = (self.u, self.u_new) if par == 0 else (self.u_new, self.u)
+
+        def seg_contract():
+            for b, blk in enumerate(self.blocks):
+                be.mode0_contract(self.X2[b], u, blk.has_miss, out=self.Zs[b])   # tpls.py:80-83
+
+        def seg_colscale():
+            for b, blk in enumerate(self.blocks):
+                if blk.has_miss:
+                    be.colscale(self.Zs[b], blk.colcnt, self.n_total)            # missingvals.py:17-19
+
+        def seg_loadings_scores():
             for b, blk in enumerate(self.blocks):
                 self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b], info=self.status[1 + 2 * b: 3 + 2 * b],
                                 n_squarings=self.sq_budget[b], fac=self.fac[b], tol=self.tol)   # tpls.py:84-90
@@ -362,16 +404,44 @@ class FitRun:
             if self.t.data_ptr() != self.Ts.data_ptr():
                 be.scores_mean(self.Ts, self.t)                                  # cmtf.py:120
             be.gram_tn(self.Y, self.t, out=self.q)                               # tpls.py:100
-            comm.allreduce(self.q)
+
+        def seg_y_update():
             be.normalize(self.q)                                                 # tpls.py:101
-            be.rowdot(self.Y, self.q, self.u_new, self.u if it > 0 else None, du2=self.status[0:1])   # tpls.py:102
-            if it > 0:
-                comm.allreduce(self.status[0:1])
+            if sharded:
+                # |u_old - u|^2 = dq^T (Y^T Y) dq with the all-reduced Gram: no third collective
+                be.rowdot(self.Y, self.q, u_new, None)                           # tpls.py:102
+                if it > 0:
+                    be.quadform(self.Gy, self.q, self.q_prev, self.status[0:1])  # tpls.py:103
+                self.q_prev.copy_(self.q)
+            else:
+                be.rowdot(self.Y, self.q, u_new, u if it > 0 else None, du2=self.status[0:1])   # tpls.py:102-103
+
+        first = True
+        while True:
+            budgets = tuple(self.sq_budget)
+            if not sharded:
+                def whole():
+                    if first:
+                        seg_contract()
+                        seg_colscale()
+                    seg_loadings_scores()
+                    seg_y_update()
+                self._run(("iter", it > 0, par, budgets, first), whole)
+            else:
+                if first:
+                    self._run(("contract", par), seg_contract)
+                    for b in range(len(self.blocks)):
+                        comm.allreduce(self.Zs[b])
+                    seg_colscale()
+                self._run(("loadings", budgets), seg_loadings_scores)
+                comm.allreduce(self.q)
+                self._run(("yupdate", it > 0, par), seg_y_update)
             host = self.status.cpu().numpy()
             if not self._update_budgets(host):
                 break
-        self.u, self.u_new = self.u_new, self.u
-        return None if it == 0 else math.sqrt(float(host[0]))                    # tpls.py:103
+            first = False
+        self._parity ^= 1
+        return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))          # tpls.py:103
 
     def finish_component(self, a: int) -> None:
         be, comm = self.eng.be, self.eng.comm
@@ -396,6 +466,9 @@ class FitRun:
                 for b, blk in enumerate(self.blocks):
                     ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))
             be.rowdot(self.Y, self.q, self.u, None)                              # u = Y q (tpls.py:102)
+        if self.algorithm == "direct" and self._parity == 1:
+            self.u, self.u_new = self.u_new, self.u      # make self.u the current u again
+            self._parity = 0
         self.T[:, a].copy_(self.t)
         self.U[:, a].copy_(self.u)
         self.Q[:, a].copy_(self.q)

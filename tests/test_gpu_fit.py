@@ -317,3 +317,26 @@ def test_xcov_algorithm_on_gpu(api, case):
         assert_allclose(m.R2X, fit.r2x[0], rtol=rtol, atol=rtol)
         assert_allclose(m.X_factors[0], d.X_factors[0], rtol=rtol, atol=rtol * np.abs(fit.T).max())
         assert_allclose(m.transform(x), m.X_factors[0], rtol=10 * rtol, atol=10 * rtol * np.abs(fit.T).max())
+
+
+def test_graph_replay_equals_eager(api):
+    """FitRun.use_graphs: the iteration's launch sequence captured into a HIP graph and replayed must
+    give bit-identical iterates to eager launches."""
+    import torch
+    from cmtf_pls_amd.backend import HipBackend
+    from cmtf_pls_amd.engine import NipalsEngine
+    x, y, _ = O.import_synthetic((512, 16, 16), 4, 3, error=0.2, seed=5)
+    outs = []
+    for graphs in (False, True):
+        eng = NipalsEngine(HipBackend("cuda:0"))
+        X = torch.from_numpy(x).to("cuda:0", torch.float32)
+        Y = torch.from_numpy(y).to("cuda:0")
+        run = eng.begin([X], Y, 3, coupled=False)
+        run.use_graphs = graphs
+        run.start_component(0)
+        dus = [run.iterate(it) for it in range(12)]
+        assert run._graph_error is None
+        outs.append((dus, run.t.clone(), run.q.clone(), run.wA[0].clone()))
+    assert outs[0][0][1:] == outs[1][0][1:]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, b)
