@@ -127,6 +127,16 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_quadform_f64(_ptr(G), G.shape[0], _ptr(q), _ptr(q_old), _ptr(out), self._stream()), "quadform")
         return out
 
+    def mttkrp(self, X2: torch.Tensor, A: int, B: int, WA: torch.Tensor, WB: torch.Tensor, out: torch.Tensor) -> Optional[torch.Tensor]:
+        """out (I, R) = X_(0) (WA (.) WB); None when R > 32 or the loadings do not fit LDS."""
+        R = WA.shape[1]
+        assert WA.is_contiguous() and WB.is_contiguous() and out.stride(1) == 1
+        rc = self._fn("mttkrp", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(WA), _ptr(WB), R, _ptr(out), out.stride(0), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "mttkrp")
+        return out
+
     # -- K3: tpls.py:92-99 / missingvals.py:23-38 --------------------------------------------
     def score(self, X2, A, B, wA, wB, rowcnt, out) -> torch.Tensor:
         _lib.check(self._fn("score", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), self._stream()), "score")

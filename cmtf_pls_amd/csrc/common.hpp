@@ -93,6 +93,23 @@ __device__ __forceinline__ double block_sum(double v, double* slot) {
   return s;
 }
 
+// Kronecker index walker: column c -> (j, k) = (c / B, c % B), advanced by a fixed stride
+struct KronWalk {
+  int j, k, dj, dk, B;
+  __device__ __forceinline__ KronWalk(int64_t c0, int64_t stride, int B_) : B(B_) {
+    j = (int)(c0 / B_);
+    k = (int)(c0 % B_);
+    dj = (int)(stride / B_);
+    dk = (int)(stride % B_);
+  }
+  __device__ __forceinline__ void next() {
+    k += dk;
+    j += dj;
+    if (k >= B) { k -= B; ++j; }
+  }
+};
+
+
 void set_error(const char* msg);
 int check_launch(const char* what);
 

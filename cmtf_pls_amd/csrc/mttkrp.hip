@@ -1,0 +1,122 @@
+// MTTKRP  M[i, r] = sum_c X[i, c] * WA[c / B, r] * WB[c % B, r]   (M = X_(0) (WA (.) WB), I x R, f64)
+// on the f64 matrix cores, the Khatri-Rao operand formed on the fly from the two loading matrices
+// staged in LDS (it is never materialised: P x R would be 1.3 MB at 128 x 128 x 10).
+//
+// Why: transform / predict (tpls.py:128-142, 151-165) project-and-deflate R times over a copy of X
+// (R reads + R writes).  Without missing values the deflations are linear, X_{a+1} = X_a - t_a w_a^T,
+// so  t_a = (X_0 w_a) - sum_{j<a} t_j (w_j . w_a)  and all scores follow from ONE pass over X:
+// T = M (I + triu(W^T W, 1))^{-1}  (engine.project does the R x R part); with coupled blocks M and
+// W^T W are averaged over blocks first (cmtf.py:155,206).
+//
+// Tile mapping (one MFMA = 16 rows of X x 16 components x 4 columns of X):
+//   lane l: ri = l & 15 (row inside the 16-row group), kq = l >> 4.
+//   the lane loads X[i0 + ri][c0 + 4*kq .. +3] as one 16-byte vector and feeds element e to MFMA e:
+//   A operand of MFMA e = X[i0 + ri][c0 + 4*kq + e]                  (A[i = l&15][k = l>>4])
+//   B operand of MFMA e = W[c0 + 4*kq + e][r = l & 15] = sA[j][r] * sB[k][r]   (B[k = l>>4][j = l&15])
+//   all four MFMAs accumulate into the same D: D[(l>>4) + 4*g][l & 15] = M[i0 + (l>>4) + 4*g][r].
+// One wavefront owns 16 whole rows (no partials, fixed summation order).
+#include "common.hpp"
+
+namespace cmtfpls {
+
+typedef double d4m_t __attribute__((ext_vector_type(4)));
+
+template <typename T, bool VEC, int RT>
+__global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, int64_t I, int A, int B,
+                                                    const double* __restrict__ WA, const double* __restrict__ WB, int R,
+                                                    double* __restrict__ out, int ldo) {
+  extern __shared__ double lds[];          // sA[A][16*RT] then sB[B][16*RT], zero padded beyond R
+  constexpr int RP = 16 * RT;
+  double* sA = lds;
+  double* sB = lds + (size_t)A * RP;
+  for (int idx = threadIdx.x; idx < A * RP; idx += 256) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
+  for (int idx = threadIdx.x; idx < B * RP; idx += 256) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ri = lane & 15, kq = lane >> 4;
+  const int64_t P = (int64_t)A * B;
+  const int64_t ngroups = (I + 15) / 16;
+  using XV = Pack<T, 4>;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t i0 = grp * 16;
+    const bool rok = (i0 + ri) < I;
+    const T* __restrict__ xr = X + ((rok ? i0 + ri : I - 1)) * P;
+    d4m_t acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = d4m_t{0.0, 0.0, 0.0, 0.0};
+    KronWalk w(4 * kq, 16, B);
+    constexpr int UN = 4;
+    for (int64_t c0 = 0; c0 < P; c0 += 16 * UN) {
+      XV x[UN];
+#pragma unroll
+      for (int s = 0; s < UN; ++s) {
+        const int64_t c = c0 + 16 * s + 4 * kq;
+        if (VEC) {
+          x[s] = ld_stream(reinterpret_cast<const XV*>(xr + ((c < P) ? c : P - 4)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[s].e[e] = xr[(c + e < P) ? c + e : P - 1];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < UN; ++s) {
+        const int64_t c = c0 + 16 * s + 4 * kq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = rok && (c + e < P);
+          const double a = ok ? (double)x[s].e[e] : 0.0;
+          int j = w.j, k = w.k + e;
+          if (!VEC && k >= B) { j += k / B; k = k % B; }   // scalar path: a 4-column group may straddle a j boundary
+          const bool wok = (c + e < P);
+#pragma unroll
+          for (int t = 0; t < RT; ++t) {
+            const double b = wok ? sA[(size_t)j * RP + t * 16 + ri] * sB[(size_t)k * RP + t * 16 + ri] : 0.0;
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+          }
+        }
+        w.next();
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t row = i0 + kq + 4 * g;
+        const int r = t * 16 + ri;
+        if (row < I && r < R) out[row * ldo + r] = acc[t][g];
+      }
+  }
+}
+
+template <typename T>
+static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, const double* WB, int R, double* out, int ldo,
+                      hipStream_t st) {
+  if (!X || !WA || !WB || !out || I <= 0 || A <= 0 || B <= 0 || R <= 0 || ldo < R) { set_error("mttkrp: bad argument"); return CMTFPLS_EINVAL; }
+  if (R > 32) { set_error("mttkrp: more than 32 components per call"); return CMTFPLS_EUNSUPPORTED; }
+  const int rt = (R + 15) / 16;
+  const size_t lds = (size_t)(A + B) * 16 * rt * sizeof(double);
+  if (lds > 96 * 1024) { set_error("mttkrp: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
+  const bool vec = (B % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) == 0);
+  const int64_t ngroups = (I + 15) / 16;
+  int grid = (int)((ngroups + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  const dim3 g(grid), b(256);
+#define ML(VC, RTT) hipLaunchKernelGGL((mttkrp_kernel<T, VC, RTT>), g, b, lds, st, X, I, A, B, WA, WB, R, out, ldo)
+  if (vec) { if (rt == 1) ML(true, 1); else ML(true, 2); }
+  else     { if (rt == 1) ML(false, 1); else ML(false, 2); }
+#undef ML
+  return check_launch("mttkrp");
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+int cmtfpls_mttkrp_f32(const float* X, int64_t I, int A, int B, const double* WA, const double* WB, int R, double* out, int ldo, void* stream) {
+  return run_mttkrp<float>(X, I, A, B, WA, WB, R, out, ldo, (hipStream_t)stream);
+}
+int cmtfpls_mttkrp_f64(const double* X, int64_t I, int A, int B, const double* WA, const double* WB, int R, double* out, int ldo, void* stream) {
+  return run_mttkrp<double>(X, I, A, B, WA, WB, R, out, ldo, (hipStream_t)stream);
+}
+}

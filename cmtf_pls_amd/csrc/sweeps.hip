@@ -193,24 +193,6 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   return check_launch("mode0_contract");
 }
 
-// ------------------------------------------------------------------------------------------
-// Kronecker index walker: column c -> (j, k) = (c / B, c % B), advanced by a fixed stride
-// ------------------------------------------------------------------------------------------
-struct KronWalk {
-  int j, k, dj, dk, B;
-  __device__ __forceinline__ KronWalk(int64_t c0, int64_t stride, int B_) : B(B_) {
-    j = (int)(c0 / B_);
-    k = (int)(c0 % B_);
-    dj = (int)(stride / B_);
-    dk = (int)(stride % B_);
-  }
-  __device__ __forceinline__ void next() {
-    k += dk;
-    j += dj;
-    if (k >= B) { k -= B; ++j; }
-  }
-};
-
 __device__ __forceinline__ void stage_loadings(double* sA, double* sB, const double* __restrict__ wA,
                                                const double* __restrict__ wB, int A, int B) {
   for (int i = threadIdx.x; i < A; i += blockDim.x) sA[i] = wA[i];

@@ -171,7 +171,7 @@ class NipalsEngine:
         return run.result()
 
     # ------------------------------------------------------------------------------------
-    def project(self, state: FitState, Xs: List[torch.Tensor]) -> torch.Tensor:
+    def project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool = True) -> torch.Tensor:
         """Sequential project-and-deflate of new samples (tpls.py:128-142; cmtf.py:143-177).
         Xs are device copies and are consumed.  Rows are independent: no communication."""
         be = self.be
@@ -183,6 +183,10 @@ class NipalsEngine:
             rowcnt, _ = be.center(X2, blk.mean, True)
             miss = bool((rowcnt.min() < X2.shape[1] - 0.5).item()) or bool(torch.isnan(blk.mean).any().item())
             rowcnts.append(rowcnt if miss else None)
+        if one_pass and all(rc is None for rc in rowcnts):
+            scores = self._project_one_pass(state, Xs)
+            if scores is not None:
+                return scores
         scores = be.zeros(I, R)
         nb = len(Xs)
         Ts = be.empty(nb, I)
@@ -209,6 +213,40 @@ class NipalsEngine:
                     be.deflate(X.view(I, -1), blk.A, blk.B, t, was[b], wbs[b])
             scores[:, a].copy_(t)
         return scores
+
+    def _project_one_pass(self, state: FitState, Xs: List[torch.Tensor]) -> Optional[torch.Tensor]:
+        """All R scores from ONE read of every (already centred, NaN-free) block.
+
+        The deflations are linear without missing values: X_{b,a+1} = X_{b,a} - t_a w_{b,a}^T with the
+        (block-averaged) score t_a, hence X_{b,a} w_{b,a} = M_b[:, a] - sum_{j<a} t_j G_b[j, a] where
+        M_b = X_{b,0} (W_A (.) W_B) is one MTTKRP and G_b = W_b^T W_b.  Averaging over blocks
+        (cmtf.py:155,206) gives T (I + triu(mean G, 1)) = mean M: an R x R triangular solve.
+        Returns None when the MTTKRP kernel does not take the shape (caller falls back)."""
+        be = self.be
+        R = state.n_components
+        I = Xs[0].shape[0]
+        nb = len(Xs)
+        Ms = be.empty(nb, I * R)
+        Gbar = np.zeros((R, R))
+        for b, (blk, X) in enumerate(zip(state.blocks, Xs)):
+            loads = [L.cpu().numpy() for L in blk.loadings]
+            if len(blk.shape) == 2:
+                WA_h, WB_h = np.ones((1, R)), loads[0]
+            else:
+                WA_h = loads[0]
+                WB_h = loads[1]
+                for L in loads[2:]:                       # column-wise Kronecker of the remaining modes
+                    WB_h = (WB_h[:, None, :] * L[None, :, :]).reshape(-1, R)
+            WA = torch.from_numpy(np.ascontiguousarray(WA_h)).to(X.device)
+            WB = torch.from_numpy(np.ascontiguousarray(WB_h)).to(X.device)
+            if be.mttkrp(X.view(I, -1), blk.A, blk.B, WA, WB, Ms[b].view(I, R)) is None:
+                return None
+            Gbar += (WA_h.T @ WA_h) * (WB_h.T @ WB_h)
+        Gbar /= nb
+        Mbar = be.scores_mean(Ms, be.empty(I * R)).view(I, R) if nb > 1 else Ms[0].view(I, R)
+        tri = np.eye(R) + np.triu(Gbar, 1)
+        T = np.linalg.solve(tri.T, Mbar.cpu().numpy().T).T      # T (I + U) = M
+        return torch.from_numpy(np.ascontiguousarray(T))
 
 
 class FitRun:

@@ -108,6 +108,16 @@ int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int
                      int masked, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream);
 
+/* mttkrp: M (I x R, leading dim ldo) = X_(0) (WA (.) WB), M[i, r] = sum_c X[i,c] WA[c / B, r] WB[c % B, r],
+ * WA (A x R) and WB (B x R) row-major f64, R <= 32, on the f64 matrix cores with the Khatri-Rao
+ * operand formed on the fly in LDS.  One pass over X replaces the R project-and-deflate passes of
+ * predict / transform (tpls.py:133-142, 156-165) when X has no NaN:
+ * T = M (I + triu(W^T W, 1))^{-1} (the R x R part is done by the caller). */
+int cmtfpls_mttkrp_f32(const float* X, int64_t I, int A, int B, const double* WA, const double* WB, int R,
+                       double* out, int ldo, void* stream);
+int cmtfpls_mttkrp_f64(const double* X, int64_t I, int A, int B, const double* WA, const double* WB, int R,
+                       double* out, int ldo, void* stream);
+
 /* ---- K3 score contraction: multi_mode_dot(X, [w...], range(1, X.ndim))  tpls.py:97-99 ---------
  * t[i] = sum_c X[i,c] * wA[c / B] * wB[c % B].
  * rowcnt != NULL selects the masked form miss_mmodedot (missingvals.py:23-38): NaN entries

@@ -59,6 +59,11 @@ class NumpyBackend:
         out[0] = float(d @ G @ d)
         return out
 
+    def mttkrp(self, X2, A, B, WA, WB, out):
+        W = (_np(WA)[:, None, :] * _np(WB)[None, :, :]).reshape(A * B, -1)
+        out.copy_(torch.from_numpy(_np(X2).astype(np.float64) @ W))
+        return out
+
     def colscale(self, Z, colcnt, n_samples):
         z, c = _np(Z), _np(colcnt)
         with np.errstate(all="ignore"):

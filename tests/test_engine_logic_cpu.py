@@ -7,6 +7,7 @@ the -m gpu tests.
 """
 import numpy as np
 import pytest
+import torch
 
 import oracle as O
 from cmtf_pls_amd import ctPLS, tPLS
@@ -185,3 +186,30 @@ def test_xcov_algorithm_equals_direct(case):
     np.testing.assert_allclose(b.coef_, a.coef_, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(r2b, r2a, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(b.R2Y, a.R2Y, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("case", ["tpls3", "tpls4", "matrix", "coupled"])
+def test_one_pass_projection_equals_sequential(case):
+    """transform/predict through one MTTKRP + R x R triangular solve == R project-and-deflate passes."""
+    from cmtf_pls_amd.tpls import to_device_copy
+    rng = np.random.default_rng(41)
+    if case == "coupled":
+        Xs = [rng.random((15, 6, 5, 4)), rng.random((15, 7, 3)), rng.random((15, 9))]
+        Y = rng.random((15, 4))
+        m = ctPLS(5, backend=NumpyBackend())
+        m.fit(Xs, Y)
+        new = [rng.random((8,) + x.shape[1:]) for x in Xs]
+        want = O.transform(O.fit_ctpls(Xs, Y, 5), new)
+    else:
+        shape = {"tpls3": (20, 8, 6), "tpls4": (20, 6, 5, 4), "matrix": (20, 30)}[case]
+        X, Y = rng.random(shape), rng.random((20, 4))
+        m = tPLS(5, backend=NumpyBackend())
+        m.fit(X, Y)
+        new = [rng.random((8,) + shape[1:])]
+        want = O.transform(O.fit_tpls(X, Y, 5), new[0])
+    eng = m._get_engine()
+    dev = lambda xs: [to_device_copy(x, torch.float64, "cpu") for x in xs]
+    one = eng.project(m._state, dev(new), one_pass=True).numpy()
+    seq = eng.project(m._state, dev(new), one_pass=False).numpy()
+    np.testing.assert_allclose(one, seq, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(one, want, rtol=1e-7, atol=1e-9)

@@ -340,3 +340,41 @@ def test_graph_replay_equals_eager(api):
     assert outs[0][0][1:] == outs[1][0][1:]
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["tpls3", "tpls3_f32", "tpls4", "matrix", "coupled"])
+def test_one_pass_projection_on_gpu(api, case):
+    """transform/predict through one MFMA MTTKRP pass + the R x R triangular recurrence must equal
+    the R sequential project-and-deflate passes (tpls.py:133-142) and the oracle."""
+    import torch
+    from cmtf_pls_amd.tpls import to_device_copy
+    rng = np.random.default_rng(41)
+    dtype, rtol = (torch.float32, 2e-5) if case.endswith("f32") else (torch.float64, 1e-8)
+    if case == "coupled":
+        Xs = [rng.random((40, 6, 5, 4)), rng.random((40, 7, 8)), rng.random((40, 9))]
+        Y = rng.random((40, 4))
+        m = api.ctPLS(5)
+        m.fit(Xs, Y)
+        new = [rng.random((24,) + x.shape[1:]) for x in Xs]
+        want = O.transform(O.fit_ctpls(Xs, Y, 5), new)
+        got_api = m.transform(new)
+    else:
+        shape = {"tpls3": (64, 16, 12), "tpls3_f32": (64, 16, 12), "tpls4": (30, 6, 5, 4), "matrix": (30, 40)}[case]
+        X, Y = rng.random(shape), rng.random((shape[0], 4))
+        if case.endswith("f32"):
+            X = X.astype(np.float32).astype(np.float64)
+        m = api.tPLS(5, dtype="float32" if case.endswith("f32") else "float64")
+        m.fit(X, Y)
+        new = [rng.random((24,) + shape[1:])]
+        if case.endswith("f32"):
+            new = [new[0].astype(np.float32).astype(np.float64)]
+        want = O.transform(O.fit_tpls(X, Y, 5), new[0])
+        got_api = m.transform(new[0])
+    eng = m._get_engine()
+    dev = lambda xs: [to_device_copy(x, dtype, "cuda:0") for x in xs]
+    one = eng.project(m._state, dev(new), one_pass=True).cpu().numpy()
+    seq = eng.project(m._state, dev(new), one_pass=False).cpu().numpy()
+    scale = np.abs(want).max()
+    assert_allclose(one, seq, rtol=rtol, atol=rtol * scale)
+    assert_allclose(one, want, rtol=max(rtol, 1e-6), atol=max(rtol, 1e-6) * scale)
+    assert_allclose(got_api, one, rtol=1e-12, atol=1e-12)

@@ -345,3 +345,18 @@ def test_xcov_identities_and_quadform(be):
     G = be.gram_tn(Y, Y)
     out = be.quadform(G, dev(q), dev(q2), be.empty(1))
     np.testing.assert_allclose(host(out)[0], np.sum((y @ q - y @ q2) ** 2), rtol=1e-11)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("shape,R", [((37, 10, 8), 3), ((100, 38, 65), 8), ((64, 1, 20), 5), ((33, 1, 7), 2),
+                                     ((50, 128, 128), 10), ((29, 5, 4), 16), ((70, 12, 8), 17), ((300, 16, 16), 32)])
+def test_mttkrp_mfma(be, shape, R, dt):
+    """M = X_(0) (WA (.) WB) on the f64 matrix cores, Khatri-Rao operand formed in LDS, against NumPy
+    (asymmetric random data: checks the A/B/D lane maps; ragged rows, odd B, 1 and 2 component tiles)."""
+    I, A, B = shape
+    x = make_x(shape, dt, seed=19)
+    rng = np.random.default_rng(20)
+    WA, WB = rng.normal(size=(A, R)), rng.normal(size=(B, R))
+    out = be.mttkrp(dev(x, TDT[dt]), A, B, dev(WA), dev(WB), be.empty(I, R))
+    W = (WA[:, None, :] * WB[None, :, :]).reshape(A * B, R)
+    np.testing.assert_allclose(host(out), x @ W, rtol=1e-11, atol=1e-10)

@@ -72,6 +72,13 @@ def main():
     wA, wB = be.empty(A), be.empty(B)
     Zm = torch.randn(P, device="cuda:0", dtype=torch.float64, generator=g)
     rec("rank1 (A x B)", lambda: be.rank1(Zm, A, B, wA, wB), P * 8)
+    S = be.empty(args.M, P)
+    rec(f"xcov S=X^T Y (M={args.M}, f64 MFMA)", lambda: be.xcov(X, Y, False, out=S), xbytes)
+    R = 10
+    WAm = torch.randn(A, R, device="cuda:0", dtype=torch.float64, generator=g)
+    WBm = torch.randn(B, R, device="cuda:0", dtype=torch.float64, generator=g)
+    Mo = be.empty(I, R)
+    rec(f"mttkrp X(WA.WB) (R={R}, f64 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo), xbytes)
     rec("gram_tn Y^T t", lambda: be.gram_tn(Y, t), I * args.M * 8)
     rec("rowdot u = Y q (+du2)", lambda: be.rowdot(Y, q, un, u), I * args.M * 8)
 

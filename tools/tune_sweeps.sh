@@ -12,7 +12,7 @@ if [ "${1:-build}" = build ]; then
   for v in "${VARIANTS[@]}"; do
     name="${v%%:*}"; flags="${v#*:}"
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags \
-        "$SRC/runtime.hip" "$SRC/sweeps.hip" "$SRC/small.hip" "$SRC/rank1.hip" "$SRC/rank1_tensor.hip" "$SRC/xcov.hip" -o "$OUT/libcmtfpls_$name.so" ) &
+        "$SRC/runtime.hip" "$SRC/sweeps.hip" "$SRC/small.hip" "$SRC/rank1.hip" "$SRC/rank1_tensor.hip" "$SRC/xcov.hip" "$SRC/mttkrp.hip" -o "$OUT/libcmtfpls_$name.so" ) &
   done
   wait
   ls -la "$OUT"
