@@ -213,3 +213,18 @@ def test_one_pass_projection_equals_sequential(case):
     seq = eng.project(m._state, dev(new), one_pass=False).numpy()
     np.testing.assert_allclose(one, seq, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(one, want, rtol=1e-7, atol=1e-9)
+
+
+def test_get_q2y_leave_one_out():
+    """validate.get_q2y (validate.py:7-37) against a literal LOO loop over the oracle."""
+    from cmtf_pls_amd.validate import get_q2y
+    x, y, _ = O.import_synthetic((14, 5, 4), 2, 2, error=0.3, seed=6)
+    m = tPLS(2, backend=NumpyBackend())
+    m.fit(x, y)
+    got = get_q2y(m)
+    pred = np.zeros_like(y)
+    for i in range(14):
+        keep = np.arange(14) != i
+        pred[i] = O.predict(O.fit_tpls(x[keep], y[keep], 2), x[i:i + 1])[0]
+    want = 1 - ((pred - y) ** 2).sum() / (y ** 2).sum()
+    np.testing.assert_allclose(got, want, rtol=1e-8)
