@@ -366,11 +366,17 @@ __global__ __launch_bounds__(kSweepThreads) void center_kernel(
 // ------------------------------------------------------------------------------------------
 // score + deflate fused: one workgroup per row, the row stays in registers between the phases
 // ------------------------------------------------------------------------------------------
-template <typename T, bool MASKED, bool VEC, int NV, int MAXT>
+// KC ("k constant"): the workgroup stride is a multiple of B, so every vector a lane owns has the
+// same k = c % B (its wB entries live in registers for the whole kernel) and j advances by a uniform
+// stride / B.  This is the shape of every power-of-two benchmark configuration and keeps the
+// 1024-thread variant (a 256 KB row in registers) inside 128 VGPRs without spilling.
+template <typename T, bool MASKED, bool VEC, int NV, int MAXT, int MODE>
 __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
     T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ wA,
     const double* __restrict__ wB, const double* __restrict__ rowcnt, double* __restrict__ t,
     double* __restrict__ ssq_part) {
+  constexpr bool KC = MODE >= 1;     // stride % B == 0
+  constexpr bool FULL = MODE == 2;   // and the workgroup covers the row exactly: no column guards
   extern __shared__ double lds[];
   __shared__ double red[2][16];
   __shared__ double red2[16];
@@ -385,6 +391,10 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
   const unsigned c0 = threadIdx.x * V;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   const KronWalk w0(c0, stride, B);   // row independent; re-walked per phase (cheaper than 2*NV registers)
+  const int dj = KC ? (int)(stride / (unsigned)B) : 0;
+  double wbv[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) wbv[e] = KC ? sB[(w0.k + e < B) ? w0.k + e : 0] : 0.0;
   double ssq = 0.0;
   int parity = 0;
   for (int64_t row = blockIdx.x; row < I; row += gridDim.x, parity ^= 1) {
@@ -392,14 +402,20 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
     VT x[NV];
 #pragma unroll
     for (int n = 0; n < NV; ++n)
-      if (c0 + n * stride < P) x[n] = ld_stream(reinterpret_cast<const VT*>(xr + c0 + n * stride));
+      if (FULL || c0 + n * stride < P) x[n] = ld_stream(reinterpret_cast<const VT*>((xr + (int64_t)n * stride) + c0));
     double acc = 0.0;
     {
       KronWalk w = w0;
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
-        if (c0 + n * stride < P) acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x[n], sB + w.k), acc);
-        w.next();
+        if (KC) {
+          int jn = w0.j + n * dj;
+          asm volatile("" : "+v"(jn));             // keep the sA read inside the row loop (no hoisting into 2*NV registers)
+          if (FULL || c0 + n * stride < P) acc = fma(sA[jn], dot_pack<T, V, MASKED>(x[n], wbv), acc);
+        } else {
+          if (c0 + n * stride < P) acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x[n], sB + w.k), acc);
+          w.next();
+        }
         if (NV > 4) __builtin_amdgcn_sched_barrier(0);   // keep live temporaries low: the row owns the VGPRs
       }
     }
@@ -410,25 +426,39 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
     for (int w = 0; w < nw; ++w) ti += red[parity][w];
     if (MASKED) ti = ti / rowcnt[row] * (double)P;
     if (threadIdx.x == 0) t[row] = ti;
+    if (sizeof(T) == 4) {
+      // make the stored row opaque here: otherwise the f64 conversions of phase 1 are kept alive
+      // across the barrier for reuse (2 extra VGPRs per element: spills at NV = 16)
+#pragma unroll
+      for (int n = 0; n < NV; ++n)
+#pragma unroll
+        for (int e = 0; e < V; ++e) asm volatile("" : "+v"(x[n].e[e]));
+    }
     {
       KronWalk w = w0;
 #pragma unroll
       for (int n = 0; n < NV; ++n) {
-        if (c0 + n * stride < P) {
-          const double tw = ti * sA[w.j];
+        int jn = KC ? w0.j + n * dj : w.j;
+        if (KC) asm volatile("" : "+v"(jn));
+        if (FULL || c0 + n * stride < P) {
+          const double tw = ti * sA[jn];
 #pragma unroll
           for (int e = 0; e < V; ++e) {
-            const T nv = (T)fma(-tw, sB[w.k + e], (double)x[n].e[e]);
+            const T nv = (T)fma(-tw, KC ? wbv[e] : sB[w.k + e], (double)x[n].e[e]);
             x[n].e[e] = nv;
             const double d = (nv == nv) ? (double)nv : 0.0;
             ssq = fma(d, d, ssq);
           }
-          st_stream(reinterpret_cast<VT*>(xr + c0 + n * stride), x[n]);
+          st_stream(reinterpret_cast<VT*>((xr + (int64_t)n * stride) + c0), x[n]);
         }
-        w.next();
+        if (!KC) w.next();
         if (NV > 4) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // 1024-thread variant: the row already fills half of the 128-VGPR budget; stop the compiler from
+    // hoisting the next row's loads above this row's stores (it does so for the 256-thread variant,
+    // which has the registers for two rows in flight)
+    if (MAXT > 256) asm volatile("" ::: "memory");
   }
   if (ssq_part) {
     const double s = block_sum(ssq, red2);
@@ -482,14 +512,14 @@ static int run_center(T* X, int64_t I, int64_t P, const double* mean, double* ro
   return check_launch("center");
 }
 
-template <typename T, bool MASKED, bool VEC>
+template <typename T, bool MASKED, bool VEC, int KC>
 static void launch_sd(int nv, int threads, size_t lds, hipStream_t st, T* X, int64_t I, int A, int B,
                       const double* wA, const double* wB, const double* rowcnt, double* t, double* ssq_part) {
   const dim3 g(kSweepBlocks), b(threads);
-  if (threads > 256) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 1024>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else if (nv == 1) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 1, 256>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else if (nv == 4) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 4, 256>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 256>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  if (threads > 256) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 1024, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (nv == 1) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 1, 256, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (nv == 4) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 4, 256, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 256, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
 }
 
 template <typename T>
@@ -506,10 +536,16 @@ static int run_score_deflate(T* X, int64_t I, int A, int B, const double* wA, co
   if (P > (int64_t)256 * V * 16) { threads = 1024; nv = 16; }
   if (P > (int64_t)threads * V * 16) { set_error("score_deflate: row does not fit one workgroup; use score + deflate"); return CMTFPLS_EUNSUPPORTED; }
   while ((int64_t)threads * V * nv < P) nv *= 4;   // 1, 4, 16
-  if (m && v) launch_sd<T, true, true>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else if (m) launch_sd<T, true, false>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else if (v) launch_sd<T, false, true>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else launch_sd<T, false, false>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  const bool kc = v && ((threads * V) % B == 0);
+  const bool full = kc && ((int64_t)threads * V * nv == P);
+  if (m && full) launch_sd<T, true, true, 2>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (m && kc) launch_sd<T, true, true, 1>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (m && v) launch_sd<T, true, true, 0>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (m) launch_sd<T, true, false, 0>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (full) launch_sd<T, false, true, 2>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (kc) launch_sd<T, false, true, 1>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (v) launch_sd<T, false, true, 0>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else launch_sd<T, false, false, 0>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
   return check_launch("score_deflate");
 }
 

@@ -400,7 +400,8 @@ class FitRun:
         fn()                                   # eager: does this call's work and sizes every workspace
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: an RCCL watchdog thread polling events must not invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self._graphs[key] = g
         except Exception as e:                 # capture unsupported in this context: stay eager
