@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, in
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = d4m_t{0.0, 0.0, 0.0, 0.0};
     KronWalk w(4 * kq, 16, B);
-    constexpr int UN = 4;
+#ifndef CMTFPLS_MTTKRP_UN
+#define CMTFPLS_MTTKRP_UN 4
+#endif
+    constexpr int UN = CMTFPLS_MTTKRP_UN;
     for (int64_t c0 = 0; c0 < P; c0 += 16 * UN) {
       XV x[UN];
 #pragma unroll

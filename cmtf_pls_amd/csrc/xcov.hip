@@ -31,10 +31,13 @@ struct XcovPlan {
 static XcovPlan plan_xcov(int64_t I, int64_t P) {
   XcovPlan p;
   p.col_tiles = (int)((P + 255) / 256);                 // 4 waves x 64 columns per workgroup
-  int64_t want = (1024 + p.col_tiles - 1) / p.col_tiles;
+#ifndef CMTFPLS_XCOV_BLOCKS
+#define CMTFPLS_XCOV_BLOCKS 1024
+#endif
+  int64_t want = (CMTFPLS_XCOV_BLOCKS + p.col_tiles - 1) / p.col_tiles;
   if (want < 1) want = 1;
   int64_t rpb = (I + want - 1) / want;
-  rpb = (rpb + 15) / 16 * 16;                            // multiple of the 4-row step x unroll
+  rpb = (rpb + 63) / 64 * 64;                            // multiple of the 4-row step x unroll x 2 stages
   if (rpb < 64) rpb = 64;
   p.rows_per_block = (int)rpb;
   p.row_blocks = (int)((I + rpb - 1) / rpb);
@@ -66,7 +69,10 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
   // Every load is unconditional (clamped address) and masked afterwards: a guarded load makes hipcc
   // branch around it and wait vmcnt(0) per load, which serialises the whole stream.  Two register
   // stages: the loads of the next 16-row step are in flight while the MFMAs of the current one run.
-  constexpr int UN = 4;
+#ifndef CMTFPLS_XCOV_UN
+#define CMTFPLS_XCOV_UN 4
+#endif
+  constexpr int UN = CMTFPLS_XCOV_UN;
   const int64_t cc = (c < P) ? c : (VEC ? P - 4 : P - 1);
   int ycol[MT];
 #pragma unroll

@@ -378,3 +378,51 @@ def test_one_pass_projection_on_gpu(api, case):
     assert_allclose(one, seq, rtol=rtol, atol=rtol * scale)
     assert_allclose(one, want, rtol=max(rtol, 1e-6), atol=max(rtol, 1e-6) * scale)
     assert_allclose(got_api, one, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_edge_shapes(api, algorithm):
+    """1-D y (M = 1), a single new sample, more responses than the xcov kernel takes (falls back to
+    the direct loop), more components than one MTTKRP call takes (falls back to sequential)."""
+    x, y, _ = O.import_synthetic((40, 6, 5), 1, 2, error=0.1, seed=3)
+    assert y.ndim == 1
+    m = api.tPLS(2, algorithm=algorithm)
+    m.fit(x, y)
+    fit = O.fit_tpls(x, y, 2)
+    assert_allclose(m.X_factors[0], fit.T, rtol=1e-7, atol=1e-8)
+    assert_allclose(m.R2Y, fit.r2y, rtol=1e-7, atol=1e-9)
+    assert_allclose(m.predict(x[:1]), O.predict(fit, x[:1]), rtol=1e-7, atol=1e-8)       # one sample
+    # 70 responses: xcov is built for M <= 64 and must fall back, results unchanged
+    rng = np.random.default_rng(4)
+    X, Y = rng.random((30, 5, 4)), rng.random((30, 70))
+    m2 = api.tPLS(3, algorithm=algorithm)
+    m2.fit(X, Y)
+    f2 = O.fit_tpls(X, Y, 3)
+    assert_allclose(m2.X_factors[0], f2.T, rtol=1e-6, atol=1e-8)
+    # 35 components (> 32 per MTTKRP call): transform falls back to the sequential path
+    Xw, Yw = rng.random((60, 8, 6)), rng.random((60, 40))
+    m3 = api.tPLS(35, algorithm=algorithm)
+    m3.fit(Xw, Yw, max_iter=5)
+    assert np.allclose(m3.transform(Xw), m3.X_factors[0], rtol=1e-6, atol=1e-8)
+
+
+def test_torch_device_inputs_and_q2y(api):
+    """Device tensors are accepted as inputs (cloned, never modified); validate.get_q2y runs its
+    leave-one-out refits on the GPU and matches a literal LOO over the oracle."""
+    import torch
+    from cmtf_pls_amd.validate import get_q2y
+    x, y, _ = O.import_synthetic((14, 5, 4), 2, 2, error=0.3, seed=6)
+    Xd, Yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m = api.tPLS(2)
+    m.fit(Xd, Yd)
+    assert torch.equal(Xd.cpu(), torch.from_numpy(x))
+    fit = O.fit_tpls(x, y, 2)
+    assert_allclose(m.X_factors[0], fit.T, rtol=1e-7, atol=1e-8)
+    mh = api.tPLS(2)
+    mh.fit(x, y)
+    pred = np.zeros_like(y)
+    for i in range(14):
+        keep = np.arange(14) != i
+        pred[i] = O.predict(O.fit_tpls(x[keep], y[keep], 2), x[i:i + 1])[0]
+    want = 1 - ((pred - y) ** 2).sum() / (y ** 2).sum()
+    assert_allclose(get_q2y(mh), want, rtol=1e-6)

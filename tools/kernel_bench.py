@@ -55,6 +55,14 @@ def main():
         rows.append((name, med, best, nbytes / med / 1e6))
         print(f"{name:28s} median {med:8.3f} ms  best {best:8.3f} ms  {nbytes/med/1e6:8.1f} GB/s (alg. bytes {nbytes/1e9:.3f} GB)", flush=True)
 
+    if args.only == "mfma":
+        S = be.empty(args.M, P)
+        rec(f"xcov S=X^T Y (M={args.M}, f64 MFMA)", lambda: be.xcov(X, Y, False, out=S), xbytes)
+        WAm = torch.randn(A, 10, device="cuda:0", dtype=torch.float64, generator=g)
+        WBm = torch.randn(B, 10, device="cuda:0", dtype=torch.float64, generator=g)
+        Mo = be.empty(I, 10)
+        rec("mttkrp X(WA.WB) (R=10, f64 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo), xbytes)
+        return
     # reference point: a plain device copy of X (read + write)
     X2 = torch.empty_like(X)
     rec("torch copy (r+w)", lambda: X2.copy_(X), 2 * xbytes)
