@@ -46,26 +46,10 @@ def parse():
 
 
 def synth_shard(I_total, J, K, M, L, noise, row0, rows, device, seed=215):
-    """Reference recipe (synthetic.py:59-74): factors from default_rng(seed) in the reference's draw
-    order on the host; the dense shard and its noise are formed on the GPU (4.3 GB cannot be staged
-    through NumPy), X fp32, Y f64."""
-    rng = np.random.default_rng(seed)
-    A0 = rng.normal(0, 1, size=(I_total, L))
-    C = rng.normal(0, 1, size=(M, L))
-    BJ = rng.normal(0, 1, size=(J, L))
-    BK = rng.normal(0, 1, size=(K, L))
-    g = torch.Generator(device=device).manual_seed(1000 + row0)
-    A0d = torch.from_numpy(A0[row0:row0 + rows]).to(device)
-    KR = (torch.from_numpy(BJ).to(device)[:, None, :] * torch.from_numpy(BK).to(device)[None, :, :]).reshape(J * K, L)
-    X = torch.empty(rows, J * K, device=device, dtype=torch.float32)
-    step = 4096
-    for r in range(0, rows, step):
-        blk = (A0d[r:r + step] @ KR.T).float()
-        blk += noise * torch.randn(blk.shape, device=device, dtype=torch.float32, generator=g)
-        X[r:r + step] = blk
-    Y = A0d @ torch.from_numpy(C).to(device).T
-    Y += noise * torch.randn(Y.shape, device=device, dtype=torch.float64, generator=g)
-    return X.view(rows, J, K), Y
+    """Reference recipe (synthetic.py:59-74) with the dense shard formed on the GPU
+    (cmtf_pls_amd.synthetic.synthetic_shard_device): X fp32, Y f64."""
+    from cmtf_pls_amd.synthetic import synthetic_shard_device
+    return synthetic_shard_device((I_total, J, K), M, L, error=noise, seed=seed, row0=row0, rows=rows, device=device)
 
 
 class EventTimer:

@@ -1,0 +1,118 @@
+"""BASELINE.json configs[1..3] on a real MI355X.
+
+Medium sizes (the oracle finishes in seconds): value parity with the oracle for the coupled
+(configs[2]) and 30 %-NaN (configs[3]) cases in float32 storage, both algorithms.
+Full sizes (65536 x 128 x 128 f32, 4.3 GB): size-independent properties the domain offers --
+transform(training X) reproduces the training scores (tests/test_tpls.py:145-155,
+tests/test_cmtf.py:44-50), unit-norm loadings (tests/test_tpls.py:31-36), non-decreasing R2Y,
+direct == xcov, and the deflated norm bookkeeping behind R2X.
+"""
+import numpy as np
+import pytest
+from numpy.linalg import norm
+from numpy.testing import assert_allclose
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import cmtf_pls_amd
+    return cmtf_pls_amd
+
+
+def _f32(a):
+    return a.astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_cfg3_coupled_medium_vs_oracle(api, algorithm):
+    x, y, cp = O.import_synthetic((2048, 32, 32), 16, 6, error=0.1, seed=31)
+    xm = cp.factors[0] @ np.random.default_rng(216).normal(size=(128, 6)).T + 0.1 * np.random.default_rng(5).normal(size=(2048, 128))
+    x, xm, y = _f32(x), _f32(xm), _f32(y)
+    m = api.ctPLS(3, dtype="float32", algorithm=algorithm)
+    m.fit([x, xm], y, max_iter=40)
+    fit = O.fit_ctpls([x, xm], y, 3, max_iter=40)
+    s = np.abs(fit.T).max()
+    assert_allclose(m.factor_T, fit.T, rtol=2e-5, atol=2e-5 * s)
+    assert_allclose(m.Y_factors[1], fit.Q, rtol=2e-5, atol=2e-5)
+    for b in range(2):
+        assert_allclose(m.R2Xs[b], fit.r2x[b], rtol=2e-5, atol=2e-6)
+    assert_allclose(m.R2Y, fit.r2y, rtol=2e-5, atol=2e-6)
+    assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_cfg4_nan30_medium_vs_oracle(api, algorithm):
+    x, y, _ = O.import_synthetic((2048, 32, 32), 16, 6, error=0.1, seed=32)
+    x, y = _f32(x), _f32(y)
+    x[np.random.default_rng(217).random(x.shape) < 0.3] = np.nan
+    m = api.tPLS(3, dtype="float32", algorithm=algorithm)
+    m.fit(x, y, max_iter=40)
+    fit = O.fit_tpls(x, y, 3, max_iter=40)
+    s = np.abs(fit.T).max()
+    assert m.X_hasMiss
+    assert_allclose(m.X_factors[0], fit.T, rtol=5e-5, atol=5e-5 * s)
+    assert_allclose(m.R2X, fit.r2x[0], rtol=5e-5, atol=5e-6)
+    assert_allclose(m.R2Y, fit.r2y, rtol=5e-5, atol=5e-6)
+    assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
+
+
+def _full(matrix_block=0, nan_fraction=0.0):
+    from cmtf_pls_amd.synthetic import synthetic_shard_device
+    return synthetic_shard_device((65536, 128, 128), 16, 10, error=0.1, device="cuda:0",
+                                  matrix_block=matrix_block, nan_fraction=nan_fraction)
+
+
+def test_cfg2_full_size_properties(api):
+    import torch
+    X, Y = _full()
+    m = api.tPLS(3, dtype="float32")
+    m.fit(X, Y)
+    x = api.tPLS(3, dtype="float32", algorithm="xcov")
+    x.fit(X, Y)
+    assert m.n_iter_ == x.n_iter_
+    s = np.abs(m.X_factors[0]).max()
+    assert_allclose(x.X_factors[0], m.X_factors[0], rtol=1e-5, atol=1e-5 * s)
+    assert_allclose(x.R2X, m.R2X, rtol=1e-6)
+    for f in m.X_factors[1:]:
+        assert_allclose(norm(f, axis=0), 1, rtol=1e-12)
+    assert np.all(np.diff(m.R2X) > 0) and np.all(np.diff(m.R2Y) > 0)
+    # one-pass MTTKRP transform of the training tensor reproduces the training scores
+    T = m.transform(X)
+    assert_allclose(T, m.X_factors[0], rtol=1e-4, atol=1e-5 * s)
+    # R2X bookkeeping: 1 - |X_3|^2 / |X_c|^2 equals the literal reconstruction formula on a row sample
+    rows = torch.arange(0, 65536, 16, device="cuda:0")      # 4096 rows
+    Xs = X[rows].double() - torch.from_numpy(m.X_mean).cuda()
+    Tsub = torch.from_numpy(m.X_factors[0]).cuda()[rows]
+    rec = torch.einsum("ir,jr,kr->ijk", Tsub, torch.from_numpy(m.X_factors[1]).cuda(), torch.from_numpy(m.X_factors[2]).cuda())
+    r2_sample = 1 - float(((Xs - rec) ** 2).sum()) / float((Xs ** 2).sum())
+    assert abs(r2_sample - m.R2X[-1]) < 5e-3
+
+
+def test_cfg3_full_size_coupled(api):
+    X, Y, Xm = _full(matrix_block=512)
+    m = api.ctPLS(2, dtype="float32")
+    m.fit([X, Xm], Y, max_iter=30)
+    s = np.abs(m.factor_T).max()
+    assert_allclose(m.transform([X, Xm]), m.factor_T, rtol=1e-4, atol=1e-5 * s)
+    assert m.Xs_factors[0][0] is m.Xs_factors[1][0]
+    for f in m.Xs_factors[0][1:] + m.Xs_factors[1][1:]:
+        assert_allclose(norm(f, axis=0), 1, rtol=1e-12)
+    assert np.all(np.diff(m.R2Y) > 0)
+
+
+def test_cfg4_full_size_nan30(api):
+    X, Y = _full(nan_fraction=0.3)
+    m = api.tPLS(2, dtype="float32")
+    m.fit(X, Y, max_iter=30)
+    assert m.X_hasMiss
+    s = np.abs(m.X_factors[0]).max()
+    xs = m.transform(X)                                     # NaN input: sequential masked path
+    assert_allclose(xs, m.X_factors[0], rtol=1e-4, atol=1e-5 * s)
+    assert np.all(np.diff(m.R2X) > 0) and np.all(np.diff(m.R2Y) > 0)
+    x2 = api.tPLS(2, dtype="float32", algorithm="xcov")
+    x2.fit(X, Y, max_iter=30)
+    assert_allclose(x2.X_factors[0], m.X_factors[0], rtol=1e-5, atol=1e-5 * s)
