@@ -40,7 +40,8 @@ class ctPLS(_EstimatorBase):
         self.Y_shape = tuple(Y2.shape)
         Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev) for X in Xs]
         Yd = to_device_copy(Y2, torch.float64, dev)
-        st = eng.fit(Xd, Yd, self.n_components, tol, max_iter, coupled=True, verbose=verbose, algorithm=self._algorithm)
+        st = eng.fit(Xd, Yd, self.n_components, tol, max_iter, coupled=True, verbose=verbose, algorithm=self._algorithm,
+                     use_graphs=self._graphs)
         del Xd
         self._state = st
         self.factor_T = st.T.cpu().numpy()

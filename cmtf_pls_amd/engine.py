@@ -153,12 +153,13 @@ class NipalsEngine:
         return FitRun(self, Xs, Y, n_components, coupled, algorithm)
 
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
-            coupled: bool, verbose: int = 0, algorithm: str = "direct") -> FitState:
+            coupled: bool, verbose: int = 0, algorithm: str = "direct", use_graphs: bool = False) -> FitState:
         """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy.
         algorithm: "direct" = the reference's loop (two X reads per iteration); "xcov" = the same
         iteration re-associated through S = X_(0)^T Y (one X read + one read/write per component)."""
         run = self.begin(Xs, Y, n_components, coupled, algorithm)
         run.tol = tol                                            # also handed to parafac (tpls.py:86)
+        run.use_graphs = bool(use_graphs) and getattr(self.be, "name", "") == "hip"
         for a in range(n_components):
             run.start_component(a)
             for it in range(max_iter):                           # tpls.py:79
@@ -349,11 +350,13 @@ class FitRun:
         touched (no X read, no communication: S is already global).  |u_old - u|^2 = dq^T (Y^T Y) dq."""
         be = self.eng.be
         self._executed += 1
-        for b, blk in enumerate(self.blocks):
-            be.mode0_contract(self.S[b], self.qc, False, out=self.Zs[b])         # tpls.py:80-83
-            if blk.has_miss:
-                be.colscale(self.Zs[b], blk.colcnt, self.n_total)                # missingvals.py:17-19
-        while True:
+
+        def seg(first: bool):
+            if first:
+                for b, blk in enumerate(self.blocks):
+                    be.mode0_contract(self.S[b], self.qc, False, out=self.Zs[b])     # tpls.py:80-83
+                    if blk.has_miss:
+                        be.colscale(self.Zs[b], blk.colcnt, self.n_total)            # missingvals.py:17-19
             for b, blk in enumerate(self.blocks):
                 self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b], info=self.status[1 + 2 * b: 3 + 2 * b],
                                 n_squarings=self.sq_budget[b], fac=self.fac[b], tol=self.tol)   # tpls.py:84-90
@@ -363,13 +366,15 @@ class FitRun:
             be.normalize(self.qn)                                                # tpls.py:100-101
             if it > 0:
                 be.quadform(self.Gy, self.qn, self.qc, self.status[0:1])         # tpls.py:102-103
+
+        first = True
+        while True:
+            self._run(("xcov", it > 0, tuple(self.sq_budget), first), lambda: seg(first))
             host = self.status.cpu().numpy()
             if not self._update_budgets(host):
                 break
-        if self.qn.data_ptr() == self.Tq.data_ptr():
-            self.qc.copy_(self.qn)
-        else:
-            self.qc, self.qn = self.qn, self.qc
+            first = False
+        self.qc.copy_(self.qn)                   # fixed buffers (a captured graph holds their addresses)
         return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))
 
     def _update_budgets(self, host) -> bool:
@@ -506,8 +511,8 @@ class FitRun:
                     ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))
             be.rowdot(self.Y, self.q, self.u, None)                              # u = Y q (tpls.py:102)
         if self.algorithm == "direct" and self._parity == 1:
-            self.u, self.u_new = self.u_new, self.u      # make self.u the current u again
-            self._parity = 0
+            self.u.copy_(self.u_new)                     # make self.u the current u again; the two buffers keep
+            self._parity = 0                             # their identity (captured graphs hold their addresses)
         self.T[:, a].copy_(self.t)
         self.U[:, a].copy_(self.u)
         self.Q[:, a].copy_(self.q)

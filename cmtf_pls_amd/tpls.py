@@ -43,10 +43,11 @@ def to_device_copy(X, dtype: torch.dtype, device) -> torch.Tensor:
 
 class _EstimatorBase(Mapping):
     def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None,
-                 algorithm: str = "direct"):
+                 algorithm: str = "direct", graphs: bool = False):
         super().__init__()
         self.n_components = n_components
         self._algorithm = algorithm
+        self._graphs = graphs                     # replay each iteration's launch sequence as a HIP graph
         self._dtype = dtype
         self._device = device
         self._comm = comm
@@ -115,7 +116,8 @@ class tPLS(_EstimatorBase):
         self.Y_shape = tuple(Y2.shape)
         Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev)
         Yd = to_device_copy(Y2, torch.float64, dev)
-        st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose, algorithm=self._algorithm)
+        st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose, algorithm=self._algorithm,
+                     use_graphs=self._graphs)
         del Xd
         blk = st.blocks[0]
         self._state = st

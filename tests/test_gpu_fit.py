@@ -381,6 +381,29 @@ def test_one_pass_projection_on_gpu(api, case):
 
 
 @pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+@pytest.mark.parametrize("kind", ["tpls", "ctpls_mixed"])
+def test_fit_with_graphs_is_bit_identical(api, algorithm, kind):
+    """graphs=True (every iteration's launch sequence replayed as a HIP graph) changes nothing."""
+    rng = np.random.default_rng(51)
+    if kind == "tpls":
+        x, y, _ = O.import_synthetic((400, 16, 12), 4, 3, error=0.2, seed=9)
+        a, b = api.tPLS(3, dtype="float32", algorithm=algorithm), api.tPLS(3, dtype="float32", algorithm=algorithm, graphs=True)
+        a.fit(x, y)
+        b.fit(x, y)
+        Ta, Tb = a.X_factors[0], b.X_factors[0]
+    else:
+        Xs = [rng.random((30, 6, 5, 4)), rng.random((30, 8, 4)), rng.random((30, 9))]
+        Y = rng.random((30, 3))
+        a, b = api.ctPLS(3, algorithm=algorithm), api.ctPLS(3, algorithm=algorithm, graphs=True)
+        a.fit(Xs, Y)
+        b.fit(Xs, Y)
+        Ta, Tb = a.factor_T, b.factor_T
+    assert a.n_iter_ == b.n_iter_
+    assert np.array_equal(Ta, Tb)
+    assert np.array_equal(a.coef_, b.coef_) and np.array_equal(a.R2Y, b.R2Y)
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
 def test_edge_shapes(api, algorithm):
     """1-D y (M = 1), a single new sample, more responses than the xcov kernel takes (falls back to
     the direct loop), more components than one MTTKRP call takes (falls back to sequential)."""
