@@ -213,7 +213,7 @@ def main():
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-        st = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, use_graphs=bool(args.graphs))
+        st = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False)
         torch.cuda.synchronize()
         fit_s = time.perf_counter() - t1
         fit_info = {"seconds": fit_s, "n_iter": list(st.n_iter), "iters_per_sec_in_fit": sum(st.n_iter) / fit_s,
@@ -229,7 +229,7 @@ def main():
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-        sx = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov", use_graphs=bool(args.graphs))
+        sx = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov")
         torch.cuda.synchronize()
         xs = time.perf_counter() - t1
         timer.on = False
