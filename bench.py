@@ -110,11 +110,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal hooks (one-GPU box): BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device; the driver's runs use neither
+    dev_index = 0 if os.environ.get("BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from cmtf_pls_amd.backend import HipBackend
     from cmtf_pls_amd.engine import Comm, NipalsEngine
