@@ -21,7 +21,12 @@ namespace cmtfpls {
 
 typedef double d4m_t __attribute__((ext_vector_type(4)));
 
-template <typename T, bool VEC, int RT>
+#ifndef CMTFPLS_MTTKRP_UN
+#define CMTFPLS_MTTKRP_UN 4
+#endif
+
+// FAST: I % 16 == 0 and P % (16 * UN) == 0 with vector loads: no clamps, no selects.
+template <typename T, bool VEC, int RT, bool FAST>
 __global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, int64_t I, int A, int B,
                                                     const double* __restrict__ WA, const double* __restrict__ WB, int R,
                                                     double* __restrict__ out, int ldo) {
@@ -39,15 +44,12 @@ __global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, in
   using XV = Pack<T, 4>;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
     const int64_t i0 = grp * 16;
-    const bool rok = (i0 + ri) < I;
+    const bool rok = FAST || (i0 + ri) < I;
     const T* __restrict__ xr = X + ((rok ? i0 + ri : I - 1)) * P;
     d4m_t acc[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = d4m_t{0.0, 0.0, 0.0, 0.0};
     KronWalk w(4 * kq, 16, B);
-#ifndef CMTFPLS_MTTKRP_UN
-#define CMTFPLS_MTTKRP_UN 4
-#endif
     constexpr int UN = CMTFPLS_MTTKRP_UN;
     for (int64_t c0 = 0; c0 < P; c0 += 16 * UN) {
       XV x[UN];
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, in
       for (int s = 0; s < UN; ++s) {
         const int64_t c = c0 + 16 * s + 4 * kq;
         if (VEC) {
-          x[s] = ld_stream(reinterpret_cast<const XV*>(xr + ((c < P) ? c : P - 4)));
+          x[s] = ld_stream(reinterpret_cast<const XV*>(xr + ((FAST || c < P) ? c : P - 4)));
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[s].e[e] = xr[(c + e < P) ? c + e : P - 1];
@@ -66,11 +68,11 @@ __global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, in
         const int64_t c = c0 + 16 * s + 4 * kq;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool ok = rok && (c + e < P);
+          const bool ok = FAST || (rok && (c + e < P));
           const double a = ok ? (double)x[s].e[e] : 0.0;
           int j = w.j, k = w.k + e;
           if (!VEC && k >= B) { j += k / B; k = k % B; }   // scalar path: a 4-column group may straddle a j boundary
-          const bool wok = (c + e < P);
+          const bool wok = FAST || (c + e < P);
 #pragma unroll
           for (int t = 0; t < RT; ++t) {
             const double b = wok ? sA[(size_t)j * RP + t * 16 + ri] * sB[(size_t)k * RP + t * 16 + ri] : 0.0;
@@ -104,9 +106,11 @@ static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, con
   int grid = (int)((ngroups + 3) / 4);
   if (grid > 2048) grid = 2048;
   const dim3 g(grid), b(256);
-#define ML(VC, RTT) hipLaunchKernelGGL((mttkrp_kernel<T, VC, RTT>), g, b, lds, st, X, I, A, B, WA, WB, R, out, ldo)
-  if (vec) { if (rt == 1) ML(true, 1); else ML(true, 2); }
-  else     { if (rt == 1) ML(false, 1); else ML(false, 2); }
+  const bool fast = vec && (I % 16 == 0) && (((int64_t)A * B) % (16 * CMTFPLS_MTTKRP_UN) == 0);
+#define ML(VC, RTT, FS) hipLaunchKernelGGL((mttkrp_kernel<T, VC, RTT, FS>), g, b, lds, st, X, I, A, B, WA, WB, R, out, ldo)
+  if (fast) { if (rt == 1) ML(true, 1, true); else ML(true, 2, true); }
+  else if (vec) { if (rt == 1) ML(true, 1, false); else ML(true, 2, false); }
+  else     { if (rt == 1) ML(false, 1, false); else ML(false, 2, false); }
 #undef ML
   return check_launch("mttkrp");
 }

@@ -45,7 +45,9 @@ static XcovPlan plan_xcov(int64_t I, int64_t P) {
   return p;
 }
 
-template <typename T, bool MASKED, bool VEC, int MT>
+// FAST: every tile is interior (P % 256 == 0, M % 16 == 0, every row block a multiple of 32 rows):
+// no clamps and no selects, so the only VALU work per MFMA is the f32 -> f64 conversion.
+template <typename T, bool MASKED, bool VEC, int MT, bool FAST>
 __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int64_t I, int64_t P,
                                                   const double* __restrict__ Y, int ldy, int M,
                                                   double* __restrict__ part, int rows_per_block) {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
 #pragma unroll
     for (int s = 0; s < UN; ++s) {
       const int64_t row = r + 4 * s + kq;
-      const int64_t rowc = (row < r1) ? row : r1 - 1;
+      const int64_t rowc = (FAST || row < r1) ? row : r1 - 1;
       if (VEC) {
         x[s] = ld_stream(reinterpret_cast<const XV*>(X + rowc * P + cc));
       } else {
@@ -96,15 +98,15 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
   auto mma_stage = [&](const XV (&x)[UN], const double (&a)[UN][MT], int64_t r) {
 #pragma unroll
     for (int s = 0; s < UN; ++s) {
-      const bool rok = (r + 4 * s + kq) < r1;
+      const bool rok = FAST || (r + 4 * s + kq) < r1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         T xv = x[s].e[e];
         if (MASKED) xv = (xv == xv) ? xv : (T)0;
-        const double b = (rok && c + e < P) ? (double)xv : 0.0;
+        const double b = (FAST || (rok && c + e < P)) ? (double)xv : 0.0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((rok && mok[mt]) ? a[s][mt] : 0.0, b, acc[mt][e], 0, 0, 0);
+          acc[mt][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((FAST || (rok && mok[mt])) ? a[s][mt] : 0.0, b, acc[mt][e], 0, 0, 0);
       }
     }
   };
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
   for (int64_t r = r0; r < r1; r += 8 * UN) {
     load_stage(xb, ab, r + 4 * UN);       // rows past r1 are clamped on load and masked in the MFMAs
     mma_stage(xa, aa, r);
-    load_stage(xa, aa, r + 8 * UN);
+    // FAST has no clamp: the look-ahead of the last trip must stay inside this block's rows
+    load_stage(xa, aa, (FAST && r + 8 * UN >= r1) ? r : r + 8 * UN);
     mma_stage(xb, ab, r + 4 * UN);
   }
 #pragma unroll
@@ -158,10 +161,12 @@ static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, 
   const int mt = (M + 15) / 16;                          // 1, 2, 3 -> 4, 4
   double* part = static_cast<double*>(ws);
   const dim3 grid(p.col_tiles, p.row_blocks), block(256);
-#define XL(MSK, VC, MTT) hipLaunchKernelGGL((xcov_kernel<T, MSK, VC, MTT>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block)
-#define XM(MSK, VC) do { if (mt == 1) XL(MSK, VC, 1); else if (mt == 2) XL(MSK, VC, 2); else XL(MSK, VC, 4); } while (0)
-  if (masked) { if (vec) XM(true, true); else XM(true, false); }
-  else        { if (vec) XM(false, true); else XM(false, false); }
+  const bool fast = vec && (P % 256 == 0) && (M % 16 == 0) && (M / 16 != 3) && (I % p.rows_per_block == 0) &&
+                    (p.rows_per_block % (8 * 4) == 0);
+#define XL(MSK, VC, MTT, FS) hipLaunchKernelGGL((xcov_kernel<T, MSK, VC, MTT, FS>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block)
+#define XM(MSK, VC, FS) do { if (mt == 1) XL(MSK, VC, 1, FS); else if (mt == 2) XL(MSK, VC, 2, FS); else XL(MSK, VC, 4, FS); } while (0)
+  if (masked) { if (fast) XM(true, true, true); else if (vec) XM(true, true, false); else XM(true, false, false); }
+  else        { if (fast) XM(false, true, true); else if (vec) XM(false, true, false); else XM(false, false, false); }
 #undef XM
 #undef XL
   launch_reduce_rows(part, p.row_blocks, (int64_t)M * P, S, st);
