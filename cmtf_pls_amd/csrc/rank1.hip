@@ -21,6 +21,7 @@ constexpr int kPanelK = 256;    // k-chunk staged in LDS per pass
 
 struct Rank1Ctl {
   double trace[kMaxSteps + 2][kMaxTiles];  // trace[s][tile]: diagonal-tile partial traces of G_s
+  double fro[2][kMaxTiles * kMaxTiles];    // fro[s & 1][tile]: per-tile sums of squares of G_s (|G_s|_F^2 = tr(G_s^2))
   int done;                                // set once G is numerically rank one
   int final_buf;                           // which ping-pong buffer holds the final G
   int steps_used;                          // squarings actually computed
@@ -48,6 +49,18 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   __shared__ int s_done;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTile + tx;
   const int nt = (n + kTile - 1) / kTile;
+  __shared__ double fsum[4];
+  double fro_in = 0.0;
+  if (step >= 1) {
+    // |G_{s-1}|_F^2 from the per-tile sums the previous step left (fixed order: bit-reproducible)
+    const double* fp = ctl->fro[(step - 1) & 1];
+    double f = 0.0;
+    for (int i = tid; i < nt * nt; i += kTile * kTile) f += fp[i];
+    f = wave_sum(f);
+    if ((tid & 63) == 0) fsum[tid >> 6] = f;
+    __syncthreads();
+    fro_in = ((fsum[0] + fsum[1]) + fsum[2]) + fsum[3];
+  }
   if (tid == 0) {
     int done = 0;
     double scale = 1.0;
@@ -59,15 +72,11 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
         // G_s = (sc_{s-1} G_{s-1})^2 with sc_{s-1} the power-of-two scale of tr(G_{s-1}).
         double tr1;
         scale = pow2_scale_from_trace(ctl->trace[step - 1], nt, &tr1);
-        if (step >= 2) {
-          // tr(G_{s-1}) = sc_{s-2}^2 tr(G_{s-2}^2), so rho = tr(G_{s-2}^2) / tr(G_{s-2})^2 is
-          // 1 - 2*(lambda_2/lambda_1) to first order: at 1 - 1e-13 G_{s-2} is rank one to 5e-14
-          // and its square G_{s-1} (the input of this step) is converged far below eps.
-          double tr0;
-          const double sc0 = pow2_scale_from_trace(ctl->trace[step - 2], nt, &tr0);
-          const double rho = tr1 / (sc0 * sc0 * tr0 * tr0);
-          if (!(tr1 > 0.0) || rho >= 1.0 - 1e-13) done = 1;
-        }
+        // rho = tr(G^2) / tr(G)^2 of the INPUT G_{s-1} is 1 - 2*(lambda_2/lambda_1) to first order:
+        // at 1 - 1e-13 the input is rank one to 5e-14 and is taken as the result (its dominant column
+        // then still goes through one exact pass with Z in the finish kernels).
+        const double rho = fro_in / (tr1 * tr1);
+        if (!(tr1 > 0.0) || rho >= 1.0 - 1e-13) done = 1;
         if (blockIdx.x == 0 && blockIdx.y == 0) {
           if (done) { ctl->done = 1; ctl->final_buf = out_buf ^ 1; }
           else ctl->steps_used = step;
@@ -101,7 +110,17 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
     __syncthreads();
   }
   acc *= scale * scale;
-  if (i0 + ty < n && j0 + tx < n) C[(int64_t)(i0 + ty) * n + (j0 + tx)] = acc;
+  const bool inside = (i0 + ty < n && j0 + tx < n);
+  if (inside) C[(int64_t)(i0 + ty) * n + (j0 + tx)] = acc;
+  {
+    // this tile's contribution to |G_s|_F^2
+    double sq = inside ? acc * acc : 0.0;
+    sq = wave_sum(sq);
+    __syncthreads();                       // fsum is free again (read before the first barrier above)
+    if ((tid & 63) == 0) fsum[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) ctl->fro[step & 1][blockIdx.y * nt + blockIdx.x] = ((fsum[0] + fsum[1]) + fsum[2]) + fsum[3];
+  }
   if (blockIdx.x == blockIdx.y) {
     if (tx == ty) diag[tx] = (i0 + ty < n) ? acc : 0.0;
     __syncthreads();

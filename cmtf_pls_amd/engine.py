@@ -387,8 +387,9 @@ class FitRun:
                 retry = True
             elif conv and len(self.blocks[b].shape) == 3:
                 # hysteresis keeps the launch sequence (and a captured graph of it) stable
-                if used + 2 > self.sq_budget[b] or used + 6 < self.sq_budget[b]:
-                    self.sq_budget[b] = min(self.sq_max, used + 3)
+                # convergence is seen by launch used + 1; keep one spare, re-plan only outside [used+1, used+4]
+                if used + 1 > self.sq_budget[b] or used + 4 < self.sq_budget[b]:
+                    self.sq_budget[b] = min(self.sq_max, used + 2)
         return retry
 
     def _run(self, key, fn) -> None:
