@@ -5,8 +5,10 @@ Layout: each X block lives on the GPU as a C-order (I_local, P) matrix (its mode
 free view), f32 or f64; Y, the scores T/U and every reduced quantity are f64.  With several
 processes (one per GPU) the SAMPLE mode is sharded: every rank holds I_local rows of every block
 and of Y, the loadings are replicated, and the only communication is an all-reduce(sum) of
- - Z (P doubles) and Y^T t (M doubles) and |du|^2 (1 double) per NIPALS iteration,
- - T^T[T|u] and two squared norms per component, column sums/counts once per fit.
+ - Z (P doubles) and Y^T t (M doubles) per direct NIPALS iteration (|du|^2 comes from the quadratic
+   form dq^T (Y^T Y) dq with the once-per-component all-reduced Gram matrix: no third collective),
+ - T^T[T|u] and two squared norms per component, column sums/counts once per fit,
+ - with algorithm="xcov": S = X_(0)^T Y (M x P doubles) once per component and NOTHING per iteration.
 All ranks run the identical rank-1 extraction on the identical all-reduced Z, so the loadings stay
 bit-identical without being communicated.
 
