@@ -16,3 +16,8 @@ done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libcmtfpls.so" "${objs[@]}"
 echo "built $OUT/libcmtfpls.so"
+# torch-free demo of the C ABI (run by tests/test_gpu_c_abi_demo.py on the GPU box)
+ROOT="$HERE/../.."
+"$HIPCC" --offload-arch=gfx950 -O2 -std=c++17 "$ROOT/examples/c_abi_demo.cpp" -L"$OUT" -lcmtfpls \
+  -Wl,-rpath,'$ORIGIN/../cmtf_pls_amd/lib' -o "$ROOT/examples/c_abi_demo"
+echo "built $ROOT/examples/c_abi_demo"

@@ -1,0 +1,17 @@
+"""The C ABI without torch: examples/c_abi_demo.cpp (hipMalloc buffers, host-loop check) built against
+libcmtfpls.so by csrc/build.sh, run here on the GPU box."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_demo_runs():
+    exe = os.path.join(ROOT, "examples", "c_abi_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "C ABI demo OK" in out.stdout
