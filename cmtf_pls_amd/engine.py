@@ -299,6 +299,11 @@ class FitRun:
         # per-iteration status read back in ONE device->host copy: [|du|^2, (converged, squarings) per block]
         self.status = be.zeros(1 + 2 * len(self.blocks))
         self.status[1::2] = 1.0
+        # pinned mirror: the read-back is an async copy on the launch stream (a memcpy node when the
+        # iteration is replayed as a graph) followed by one stream synchronisation
+        self.status_host = None
+        if self.status.is_cuda:
+            self.status_host = torch.empty(self.status.shape, dtype=torch.float64, pin_memory=True)
         self.sq_max = int(getattr(be, "rank1_squarings", 30))
         self.sq_budget = [self.sq_max] * len(self.blocks)
         self.u = be.empty(I)
@@ -372,7 +377,7 @@ class FitRun:
         first = True
         while True:
             self._run(("xcov", it > 0, tuple(self.sq_budget), first), lambda: seg(first))
-            host = self.status.cpu().numpy()
+            host = self._read_status()
             if not self._update_budgets(host):
                 break
             first = False
@@ -393,6 +398,13 @@ class FitRun:
                 if used + 1 > self.sq_budget[b] or used + 4 < self.sq_budget[b]:
                     self.sq_budget[b] = min(self.sq_max, used + 2)
         return retry
+
+    def _read_status(self) -> np.ndarray:
+        if self.status_host is None:
+            return self.status.cpu().numpy()
+        self.status_host.copy_(self.status, non_blocking=True)
+        torch.cuda.current_stream(self.status.device).synchronize()
+        return self.status_host.numpy()
 
     def _run(self, key, fn) -> None:
         """Run one launch sequence; with use_graphs it is captured once per key into a HIP graph
@@ -483,7 +495,7 @@ class FitRun:
                 self._run(("loadings", budgets), seg_loadings_scores)
                 comm.allreduce(self.q)
                 self._run(("yupdate", it > 0, par), seg_y_update)
-            host = self.status.cpu().numpy()
+            host = self._read_status()
             if not self._update_budgets(host):
                 break
             first = False
