@@ -247,6 +247,15 @@ def main():
                             "xcov_kernel": {"ms": xms, "alg_GB": xbytes / 1e9, "GBps": xbytes / xms / 1e6,
                                             "f64_mfma_TFLOPs": 2.0 * rows * J * K * M / xms / 1e9}}
         del Xf, Yf
+        # opt-in mixed precision of the S build (f32 MFMA, csrc/mixed.hip): reported, never the headline
+        Xf, Yf = X.clone(), Y.clone()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sm = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov", mixed=True)
+        torch.cuda.synchronize()
+        fit_info["xcov_mixed_f32mfma"] = {"seconds": time.perf_counter() - t1, "n_iter": list(sm.n_iter),
+                                          "max_abs_dT_vs_direct": float((sm.T - st.T).abs().max())}
+        del Xf, Yf
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -112,26 +112,31 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_normalize_f64(_ptr(v), v.numel(), None, self._stream()), "normalize")
 
     # -- cross-covariance form (exact re-association of the loop, see include/cmtfpls.h) --------
-    def xcov(self, X2: torch.Tensor, Y: torch.Tensor, masked: bool, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-        """S (M, P) = Y^T X_(0) on the f64 matrix cores; None when M > 64 (caller uses the direct loop)."""
+    def xcov(self, X2: torch.Tensor, Y: torch.Tensor, masked: bool, out: Optional[torch.Tensor] = None,
+             mixed: bool = False) -> Optional[torch.Tensor]:
+        """S (M, P) = Y^T X_(0) on the matrix cores (f64 MFMA; ``mixed`` = the opt-in f32-MFMA form for
+        f32-stored X); None when M > 64 (caller uses the direct loop)."""
         I, P = X2.shape
         M = Y.shape[1]
         if M > 64:
             return None
         ws = self._workspace("contract", self.lib.cmtfpls_xcov_workspace_bytes(I, P, M))
         S = out if out is not None else self.empty(M, P)
-        _lib.check(self._fn("xcov", X2)(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
+        fn = self.lib.cmtfpls_xcov_f32_mixed if (mixed and X2.dtype == torch.float32) else self._fn("xcov", X2)
+        _lib.check(fn(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
         return S
 
     def quadform(self, G: torch.Tensor, q: torch.Tensor, q_old: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.check(self.lib.cmtfpls_quadform_f64(_ptr(G), G.shape[0], _ptr(q), _ptr(q_old), _ptr(out), self._stream()), "quadform")
         return out
 
-    def mttkrp(self, X2: torch.Tensor, A: int, B: int, WA: torch.Tensor, WB: torch.Tensor, out: torch.Tensor) -> Optional[torch.Tensor]:
+    def mttkrp(self, X2: torch.Tensor, A: int, B: int, WA: torch.Tensor, WB: torch.Tensor, out: torch.Tensor,
+               mixed: bool = False) -> Optional[torch.Tensor]:
         """out (I, R) = X_(0) (WA (.) WB); None when R > 32 or the loadings do not fit LDS."""
         R = WA.shape[1]
         assert WA.is_contiguous() and WB.is_contiguous() and out.stride(1) == 1
-        rc = self._fn("mttkrp", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(WA), _ptr(WB), R, _ptr(out), out.stride(0), self._stream())
+        fn = self.lib.cmtfpls_mttkrp_f32_mixed if (mixed and X2.dtype == torch.float32) else self._fn("mttkrp", X2)
+        rc = fn(_ptr(X2), X2.shape[0], A, B, _ptr(WA), _ptr(WB), R, _ptr(out), out.stride(0), self._stream())
         if rc == 4:
             return None
         _lib.check(rc, "mttkrp")

@@ -41,7 +41,7 @@ class ctPLS(_EstimatorBase):
         Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev) for X in Xs]
         Yd = to_device_copy(Y2, torch.float64, dev)
         st = eng.fit(Xd, Yd, self.n_components, tol, max_iter, coupled=True, verbose=verbose, algorithm=self._algorithm,
-                     use_graphs=self._graphs)
+                     use_graphs=self._graphs, mixed=self._mixed)
         del Xd
         self._state = st
         self.factor_T = st.T.cpu().numpy()
@@ -67,7 +67,7 @@ class ctPLS(_EstimatorBase):
                 )
         eng = self._get_engine()
         Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device) for X in Xs]
-        return eng.project(self._state, Xd).cpu().numpy()
+        return eng.project(self._state, Xd, mixed=self._mixed).cpu().numpy()
 
     def predict(self, Xs):
         return self._project(Xs) @ self.coef_ @ self.Y_factors[1].T + self.Y_mean      # cmtf.py:177

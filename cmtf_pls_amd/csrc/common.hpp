@@ -110,6 +110,12 @@ struct KronWalk {
 };
 
 
+// launch plan shared by the f64 and the mixed-precision cross-covariance kernels (xcov.hip, mixed.hip)
+struct XcovPlan {
+  int col_tiles, row_blocks, rows_per_block;
+};
+XcovPlan plan_xcov(int64_t I, int64_t P);
+
 void set_error(const char* msg);
 int check_launch(const char* what);
 

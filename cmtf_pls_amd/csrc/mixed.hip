@@ -1,0 +1,248 @@
+// Mixed-precision variants of the two matrix-core contractions for f32-stored X (opt-in):
+//   xcov_mixed    S = Y^T X_(0)            (see xcov.hip)
+//   mttkrp_mixed  M = X_(0) (WA (.) WB)    (see mttkrp.hip)
+// on v_mfma_f32_16x16x4_f32, which issues in half the cycles of v_mfma_f64_16x16x4_f64: the f64
+// kernels are bound by the f64 matrix pipe (72-80 % busy at the clock the chip holds,
+// profiles/r01i_mfma_utilisation.json), these are bound by HBM.
+// Precision contract (why this is opt-in and the f64 kernels are the default): X is exact (it IS
+// f32); the other operand (Y, or the Khatri-Rao entry wA*wB formed in f64) is rounded once to f32
+// (relative 6e-8); products are accumulated in f32 only inside a chain of 64 rows (xcov) / 256 columns
+// (mttkrp) and every chain is then added into f64 accumulators.  The f32 MFMA is a k-ordered fmaf
+// chain (MI355X guide), so the result is deterministic.  Measured effect on a fit: see
+// tests/test_gpu_mixed.py (scores within 2e-6 relative of the f64 path).
+//
+// Tile mapping is that of the f64 kernels except for the D layout of the f32 16x16 MFMA:
+//   D[reg g] of lane l is row (l >> 4) * 4 + g, column l & 15   (f64: row (l >> 4) + 4 * g).
+#include "common.hpp"
+
+namespace cmtfpls {
+
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st);
+
+template <bool MASKED, bool VEC, int MT>
+__global__ __launch_bounds__(256) void xcov_mixed_kernel(const float* __restrict__ X, int64_t I, int64_t P,
+                                                        const double* __restrict__ Y, int ldy, int M,
+                                                        double* __restrict__ part, int rows_per_block) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kq = lane >> 4, nn = lane & 15;
+  const int64_t cb = ((int64_t)blockIdx.x * 4 + wv) * 64;
+  if (cb >= P) return;
+  const int64_t c = cb + 4 * nn;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  using XV = Pack<float, 4>;
+  f4_t acc32[MT][4];
+  double acc64[MT][4][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc32[mt][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc64[mt][e][g] = 0.0;
+    }
+  bool mok[MT];
+  int ycol[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { mok[mt] = (mt * 16 + nn) < M; ycol[mt] = mok[mt] ? mt * 16 + nn : M - 1; }
+  constexpr int UN = 4;
+  const int64_t cc = (c < P) ? c : (VEC ? P - 4 : P - 1);
+
+  auto load_stage = [&](XV (&x)[UN], float (&a)[UN][MT], int64_t r) {
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const int64_t row = r + 4 * s + kq;
+      const int64_t rowc = (row < r1) ? row : r1 - 1;
+      if (VEC) {
+        x[s] = ld_stream(reinterpret_cast<const XV*>(X + rowc * P + cc));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[s].e[e] = X[rowc * P + ((cc + e < P) ? cc + e : P - 1)];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[s][mt] = (float)Y[rowc * ldy + ycol[mt]];
+    }
+  };
+  auto mma_stage = [&](const XV (&x)[UN], const float (&a)[UN][MT], int64_t r) {
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const bool rok = (r + 4 * s + kq) < r1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xv = x[s].e[e];
+        if (MASKED) xv = (xv == xv) ? xv : 0.f;
+        const float b = (rok && c + e < P) ? xv : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc32[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32((rok && mok[mt]) ? a[s][mt] : 0.f, b, acc32[mt][e], 0, 0, 0);
+      }
+    }
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc64[mt][e][g] += (double)acc32[mt][e][g];
+        acc32[mt][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+
+  XV xa[UN], xb[UN];
+  float aa[UN][MT], ab[UN][MT];
+  load_stage(xa, aa, r0);
+  int trip = 0;
+  for (int64_t r = r0; r < r1; r += 8 * UN, ++trip) {
+    load_stage(xb, ab, r + 4 * UN);
+    mma_stage(xa, aa, r);
+    load_stage(xa, aa, r + 8 * UN);
+    mma_stage(xb, ab, r + 4 * UN);
+    if (trip & 1) flush();                 // f32 chains of 64 rows
+  }
+  flush();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = mt * 16 + kq * 4 + g;
+      if (m < M) {
+        double* dst = part + ((int64_t)blockIdx.y * M + m) * P + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < P) dst[e] = acc64[mt][e][g];
+      }
+    }
+}
+
+template <bool VEC, int RT>
+__global__ __launch_bounds__(256) void mttkrp_mixed_kernel(const float* __restrict__ X, int64_t I, int A, int B,
+                                                          const double* __restrict__ WA, const double* __restrict__ WB, int R,
+                                                          double* __restrict__ out, int ldo) {
+  extern __shared__ double lds[];
+  constexpr int RP = 16 * RT;
+  double* sA = lds;
+  double* sB = lds + (size_t)A * RP;
+  for (int idx = threadIdx.x; idx < A * RP; idx += 256) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
+  for (int idx = threadIdx.x; idx < B * RP; idx += 256) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ri = lane & 15, kq = lane >> 4;
+  const int64_t P = (int64_t)A * B;
+  const int64_t ngroups = (I + 15) / 16;
+  using XV = Pack<float, 4>;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t i0 = grp * 16;
+    const bool rok = (i0 + ri) < I;
+    const float* __restrict__ xr = X + (rok ? i0 + ri : I - 1) * P;
+    f4_t acc32[RT];
+    double acc64[RT][4];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      acc32[t] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc64[t][g] = 0.0;
+    }
+    KronWalk w(4 * kq, 16, B);
+    constexpr int UN = 4;
+    int trip = 0;
+    for (int64_t c0 = 0; c0 < P; c0 += 16 * UN, ++trip) {
+      XV x[UN];
+#pragma unroll
+      for (int s = 0; s < UN; ++s) {
+        const int64_t c = c0 + 16 * s + 4 * kq;
+        if (VEC) {
+          x[s] = ld_stream(reinterpret_cast<const XV*>(xr + ((c < P) ? c : P - 4)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[s].e[e] = xr[(c + e < P) ? c + e : P - 1];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < UN; ++s) {
+        const int64_t c = c0 + 16 * s + 4 * kq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = rok && (c + e < P);
+          const float a = ok ? x[s].e[e] : 0.f;
+          int j = w.j, k = w.k + e;
+          if (!VEC && k >= B) { j += k / B; k = k % B; }
+          const bool wok = (c + e < P);
+#pragma unroll
+          for (int t = 0; t < RT; ++t) {
+            const float b = wok ? (float)(sA[(size_t)j * RP + t * 16 + ri] * sB[(size_t)k * RP + t * 16 + ri]) : 0.f;
+            acc32[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc32[t], 0, 0, 0);
+          }
+        }
+        w.next();
+      }
+      if ((trip & 3) == 3) {               // f32 chains of 256 columns
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc64[t][g] += (double)acc32[t][g];
+          acc32[t] = f4_t{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t row = i0 + kq * 4 + g;
+        const int r = t * 16 + ri;
+        if (row < I && r < R) out[row * ldo + r] = acc64[t][g] + (double)acc32[t][g];
+      }
+  }
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+
+int cmtfpls_xcov_f32_mixed(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
+                           void* ws, size_t ws_bytes, void* stream) {
+  if (!X || !Y || !S || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov_mixed: bad argument"); return CMTFPLS_EINVAL; }
+  if (M > 64) { set_error("xcov_mixed: more than 64 responses"); return CMTFPLS_EUNSUPPORTED; }
+  const XcovPlan p = plan_xcov(I, P);
+  const size_t need = (size_t)p.row_blocks * M * P * sizeof(double);
+  if (!ws || ws_bytes < need) { set_error("xcov_mixed: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const int mt = (M + 15) / 16;
+  double* part = static_cast<double*>(ws);
+  const dim3 grid(p.col_tiles, p.row_blocks), block(256);
+#define XL(MSK, VC, MTT) hipLaunchKernelGGL((xcov_mixed_kernel<MSK, VC, MTT>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block)
+#define XM(MSK, VC) do { if (mt == 1) XL(MSK, VC, 1); else if (mt == 2) XL(MSK, VC, 2); else XL(MSK, VC, 4); } while (0)
+  if (masked) { if (vec) XM(true, true); else XM(true, false); }
+  else        { if (vec) XM(false, true); else XM(false, false); }
+#undef XM
+#undef XL
+  launch_reduce_rows(part, p.row_blocks, (int64_t)M * P, S, st);
+  return check_launch("xcov_mixed");
+}
+
+int cmtfpls_mttkrp_f32_mixed(const float* X, int64_t I, int A, int B, const double* WA, const double* WB, int R,
+                             double* out, int ldo, void* stream) {
+  if (!X || !WA || !WB || !out || I <= 0 || A <= 0 || B <= 0 || R <= 0 || ldo < R) { set_error("mttkrp_mixed: bad argument"); return CMTFPLS_EINVAL; }
+  if (R > 32) { set_error("mttkrp_mixed: more than 32 components per call"); return CMTFPLS_EUNSUPPORTED; }
+  const int rt = (R + 15) / 16;
+  const size_t lds = (size_t)(A + B) * 16 * rt * sizeof(double);
+  if (lds > 96 * 1024) { set_error("mttkrp_mixed: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
+  const bool vec = (B % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const int64_t ngroups = (I + 15) / 16;
+  int grid = (int)((ngroups + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  hipStream_t st = (hipStream_t)stream;
+#define ML(VC, RTT) hipLaunchKernelGGL((mttkrp_mixed_kernel<VC, RTT>), dim3(grid), dim3(256), lds, st, X, I, A, B, WA, WB, R, out, ldo)
+  if (vec) { if (rt == 1) ML(true, 1); else ML(true, 2); }
+  else     { if (rt == 1) ML(false, 1); else ML(false, 2); }
+#undef ML
+  return check_launch("mttkrp_mixed");
+}
+
+}  // extern "C"

@@ -24,11 +24,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 
 void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st);
 
-struct XcovPlan {
-  int col_tiles, row_blocks, rows_per_block;
-};
-
-static XcovPlan plan_xcov(int64_t I, int64_t P) {
+XcovPlan plan_xcov(int64_t I, int64_t P) {
   XcovPlan p;
   p.col_tiles = (int)((P + 255) / 256);                 // 4 waves x 64 columns per workgroup
 #ifndef CMTFPLS_XCOV_BLOCKS

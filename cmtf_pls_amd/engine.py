@@ -155,13 +155,15 @@ class NipalsEngine:
         return FitRun(self, Xs, Y, n_components, coupled, algorithm)
 
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
-            coupled: bool, verbose: int = 0, algorithm: str = "direct", use_graphs: bool = False) -> FitState:
+            coupled: bool, verbose: int = 0, algorithm: str = "direct", use_graphs: bool = False,
+            mixed: bool = False) -> FitState:
         """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy.
         algorithm: "direct" = the reference's loop (two X reads per iteration); "xcov" = the same
         iteration re-associated through S = X_(0)^T Y (one X read + one read/write per component)."""
         run = self.begin(Xs, Y, n_components, coupled, algorithm)
         run.tol = tol                                            # also handed to parafac (tpls.py:86)
         run.use_graphs = bool(use_graphs) and getattr(self.be, "name", "") == "hip"
+        run.mixed = bool(mixed)
         for a in range(n_components):
             run.start_component(a)
             for it in range(max_iter):                           # tpls.py:79
@@ -174,7 +176,7 @@ class NipalsEngine:
         return run.result()
 
     # ------------------------------------------------------------------------------------
-    def project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool = True) -> torch.Tensor:
+    def project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool = True, mixed: bool = False) -> torch.Tensor:
         """Sequential project-and-deflate of new samples (tpls.py:128-142; cmtf.py:143-177).
         Xs are device copies and are consumed.  Rows are independent: no communication."""
         be = self.be
@@ -187,7 +189,7 @@ class NipalsEngine:
             miss = bool((rowcnt.min() < X2.shape[1] - 0.5).item()) or bool(torch.isnan(blk.mean).any().item())
             rowcnts.append(rowcnt if miss else None)
         if one_pass and all(rc is None for rc in rowcnts):
-            scores = self._project_one_pass(state, Xs)
+            scores = self._project_one_pass(state, Xs, mixed)
             if scores is not None:
                 return scores
         scores = be.zeros(I, R)
@@ -217,7 +219,7 @@ class NipalsEngine:
             scores[:, a].copy_(t)
         return scores
 
-    def _project_one_pass(self, state: FitState, Xs: List[torch.Tensor]) -> Optional[torch.Tensor]:
+    def _project_one_pass(self, state: FitState, Xs: List[torch.Tensor], mixed: bool = False) -> Optional[torch.Tensor]:
         """All R scores from ONE read of every (already centred, NaN-free) block.
 
         The deflations are linear without missing values: X_{b,a+1} = X_{b,a} - t_a w_{b,a}^T with the
@@ -242,7 +244,7 @@ class NipalsEngine:
                     WB_h = (WB_h[:, None, :] * L[None, :, :]).reshape(-1, R)
             WA = torch.from_numpy(np.ascontiguousarray(WA_h)).to(X.device)
             WB = torch.from_numpy(np.ascontiguousarray(WB_h)).to(X.device)
-            if be.mttkrp(X.view(I, -1), blk.A, blk.B, WA, WB, Ms[b].view(I, R)) is None:
+            if be.mttkrp(X.view(I, -1), blk.A, blk.B, WA, WB, Ms[b].view(I, R), mixed=mixed) is None:
                 return None
             Gbar += (WA_h.T @ WA_h) * (WB_h.T @ WB_h)
         Gbar /= nb
@@ -312,6 +314,7 @@ class FitRun:
         self.n_iter: List[int] = []
         self._executed = 0
         self._parity = 0
+        self.mixed = False                        # opt-in f32-MFMA form of the S build (f32 storage only)
         self.use_graphs = False
         self._graphs = {}
         self._graph_error = None
@@ -341,11 +344,11 @@ class FitRun:
                 comm.allreduce(self.Gy)
             return
         for b, blk in enumerate(self.blocks):
-            be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b])
+            be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b], mixed=self.mixed)
             comm.allreduce(self.S[b])
             if blk.has_miss:
                 torch.mul(self.Y, self.rowscale[b][:, None], out=self.Yw)
-                be.xcov(self.X2[b], self.Yw, True, out=self.S2[b])
+                be.xcov(self.X2[b], self.Yw, True, out=self.S2[b], mixed=self.mixed)
                 comm.allreduce(self.S2[b])
         be.gram_tn(self.Y, self.Y, out=self.Gy)
         comm.allreduce(self.Gy)

@@ -43,11 +43,14 @@ def to_device_copy(X, dtype: torch.dtype, device) -> torch.Tensor:
 
 class _EstimatorBase(Mapping):
     def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None,
-                 algorithm: str = "direct", graphs: bool = False):
+                 algorithm: str = "direct", graphs: bool = False, matrix_precision: str = "f64"):
         super().__init__()
         self.n_components = n_components
         self._algorithm = algorithm
         self._graphs = graphs                     # replay each iteration's launch sequence as a HIP graph
+        if matrix_precision not in ("f64", "f32"):
+            raise ValueError("matrix_precision must be 'f64' or 'f32'")
+        self._mixed = matrix_precision == "f32"   # f32-MFMA S build / MTTKRP for f32-stored X (opt-in)
         self._dtype = dtype
         self._device = device
         self._comm = comm
@@ -117,7 +120,7 @@ class tPLS(_EstimatorBase):
         Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev)
         Yd = to_device_copy(Y2, torch.float64, dev)
         st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose, algorithm=self._algorithm,
-                     use_graphs=self._graphs)
+                     use_graphs=self._graphs, mixed=self._mixed)
         del Xd
         blk = st.blocks[0]
         self._state = st
@@ -139,7 +142,7 @@ class tPLS(_EstimatorBase):
             raise ValueError(f"Training X has shape {self.X_shape}, while the new X has shape {tuple(X.shape)}")
         eng = self._get_engine()
         Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device)
-        return eng.project(self._state, [Xd]).cpu().numpy()
+        return eng.project(self._state, [Xd], mixed=self._mixed).cpu().numpy()
 
     def predict(self, X):
         return self._project(X) @ self.coef_ @ self.Y_factors[1].T + self.Y_mean      # tpls.py:143

@@ -107,6 +107,14 @@ int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int 
 int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
                      int masked, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream);
+/* Opt-in mixed-precision forms of xcov and mttkrp for f32-stored X: v_mfma_f32_16x16x4_f32 (half the
+ * matrix cycles of the f64 form, HBM-bound instead of matrix-pipe-bound).  X is exact; the other
+ * operand is rounded once to f32; f32 accumulation only inside chains of 64 rows (xcov) / 256 columns
+ * (mttkrp), every chain added into f64.  Same arguments, workspaces and outputs as the f64 forms. */
+int cmtfpls_xcov_f32_mixed(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
+                           int masked, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_mttkrp_f32_mixed(const float* X, int64_t I, int A, int B, const double* WA, const double* WB, int R,
+                             double* out, int ldo, void* stream);
 
 /* mttkrp: M (I x R, leading dim ldo) = X_(0) (WA (.) WB), M[i, r] = sum_c X[i,c] WA[c / B, r] WB[c % B, r],
  * WA (A x R) and WB (B x R) row-major f64, R <= 32, on the f64 matrix cores with the Khatri-Rao

@@ -44,7 +44,7 @@ class NumpyBackend:
             return out
         return z
 
-    def xcov(self, X2, Y, masked, out=None):
+    def xcov(self, X2, Y, masked, out=None, mixed=False):
         x = _np(X2).astype(np.float64)
         if masked:
             x = np.where(np.isnan(x), 0.0, x)
@@ -59,7 +59,7 @@ class NumpyBackend:
         out[0] = float(d @ G @ d)
         return out
 
-    def mttkrp(self, X2, A, B, WA, WB, out):
+    def mttkrp(self, X2, A, B, WA, WB, out, mixed=False):
         W = (_np(WA)[:, None, :] * _np(WB)[None, :, :]).reshape(A * B, -1)
         out.copy_(torch.from_numpy(_np(X2).astype(np.float64) @ W))
         return out

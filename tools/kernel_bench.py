@@ -62,6 +62,9 @@ def main():
         WBm = torch.randn(B, 10, device="cuda:0", dtype=torch.float64, generator=g)
         Mo = be.empty(I, 10)
         rec("mttkrp X(WA.WB) (R=10, f64 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo), xbytes)
+        if args.dtype == "f32":
+            rec(f"xcov mixed (M={args.M}, f32 MFMA)", lambda: be.xcov(X, Y, False, out=S, mixed=True), xbytes)
+            rec("mttkrp mixed (R=10, f32 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo, mixed=True), xbytes)
         return
     # reference point: a plain device copy of X (read + write)
     X2 = torch.empty_like(X)

@@ -10,7 +10,7 @@ if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"; rm -f "$OUT"/libcmtfpls_m_*.so
   for v in "${VARIANTS[@]}"; do
     name="${v%%:*}"; flags="${v#*:}"
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags "$SRC"/{runtime,sweeps,small,rank1,rank1_tensor,xcov,mttkrp}.hip -o "$OUT/libcmtfpls_$name.so" ) &
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags "$SRC"/{runtime,sweeps,small,rank1,rank1_tensor,xcov,mttkrp,mixed}.hip -o "$OUT/libcmtfpls_$name.so" ) &
   done
   wait; ls "$OUT" | grep m_
 else
