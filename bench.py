@@ -56,13 +56,13 @@ class EventTimer:
     """Brackets backend calls with HIP events on the current (launch) stream."""
 
     def __init__(self, be, names):
-        self.be, self.records, self.on = be, {n: [] for n in names}, False
+        self.be, self.records, self.on, self.only = be, {n: [] for n in names}, False, None
         for n in names:
             setattr(be, n, self._wrap(n, getattr(be, n)))
 
     def _wrap(self, name, fn):
         def wrapped(*a, **k):
-            if not self.on:
+            if not self.on or (self.only is not None and name not in self.only):
                 return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -231,7 +231,8 @@ def main():
         Xf, Yf = X.clone(), Y.clone()
         timer.records["xcov"] = []
         be.xcov = timer._wrap("xcov", be.xcov)
-        timer.on = True
+        timer.on, timer.only = True, {"xcov"}     # bracket only the S build: markers on every tiny kernel of
+                                                  # the inner loop would perturb what is being timed
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -239,7 +240,7 @@ def main():
         sx = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov")
         torch.cuda.synchronize()
         xs = time.perf_counter() - t1
-        timer.on = False
+        timer.on, timer.only = False, None
         xms = timer.mean_ms("xcov")
         fit_info["xcov"] = {"seconds": xs, "n_iter": list(sx.n_iter), "iters_per_sec_in_fit": sum(sx.n_iter) / xs,
                             "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
