@@ -55,8 +55,14 @@ class ctPLS(_EstimatorBase):
         self.Xs_hasMiss = [blk.has_miss for blk in st.blocks]
         if any(self.Xs_hasMiss):
             print("At least one X has missing values")                    # cmtf.py:78-79
-        self.Xs_miss = [np.isnan(X) if isinstance(X, np.ndarray) else None for X in Xs]
+        self._Xs_in, self._Xs_miss = Xs, None     # Xs_miss (cmtf.py:80-82) is built on first access
         self.n_iter_ = list(st.n_iter)
+
+    @property
+    def Xs_miss(self):
+        if self._Xs_miss is None:
+            self._Xs_miss = [np.isnan(X) if isinstance(X, np.ndarray) else None for X in self._Xs_in]
+        return self._Xs_miss
 
     def _project(self, Xs) -> np.ndarray:
         assert len(Xs) == self.Xs_len                                     # cmtf.py:144,181

@@ -127,7 +127,7 @@ class tPLS(_EstimatorBase):
         self.X_hasMiss = blk.has_miss
         if self.X_hasMiss:
             print("X has missing values")                                 # tpls.py:62-63
-        self.X_miss = np.isnan(X) if isinstance(X, np.ndarray) else None
+        self._X_miss = None                       # X_miss (np.isnan(X), tpls.py:64) is built on first access
         self.X_factors = [st.T.cpu().numpy()] + [L.cpu().numpy() for L in blk.loadings]
         self.Y_factors = [st.U.cpu().numpy(), st.Q.cpu().numpy()]
         self.coef_ = st.coef
@@ -136,6 +136,14 @@ class tPLS(_EstimatorBase):
         self.X_mean = blk.mean.cpu().numpy().reshape(self.X_shape[1:])
         self.Y_mean = st.y_mean.cpu().numpy()
         self.n_iter_ = list(st.n_iter)
+
+    @property
+    def X_miss(self):
+        """Positions of missing values (tpls.py:64); computed lazily: at 65536x128x128 it is a 1 GB array
+        nothing on the fit path needs (the kernels read the NaNs in band)."""
+        if self._X_miss is None and isinstance(self.original_X, np.ndarray):
+            self._X_miss = np.isnan(self.original_X)
+        return self._X_miss
 
     def _project(self, X) -> np.ndarray:
         if self.X_shape[1:] != tuple(X.shape[1:]):

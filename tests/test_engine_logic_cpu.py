@@ -228,3 +228,15 @@ def test_get_q2y_leave_one_out():
         pred[i] = O.predict(O.fit_tpls(x[keep], y[keep], 2), x[i:i + 1])[0]
     want = 1 - ((pred - y) ** 2).sum() / (y ** 2).sum()
     np.testing.assert_allclose(got, want, rtol=1e-8)
+
+
+def test_miss_attributes_lazy():
+    rng = np.random.default_rng(3)
+    x, y = rng.random((12, 4, 3)), rng.random((12, 2))
+    x[2, 1, 1] = np.nan
+    m = tPLS(1, backend=NumpyBackend())
+    m.fit(x, y)
+    assert m.X_hasMiss and m.X_miss.shape == x.shape and m.X_miss[2, 1, 1] and m.X_miss.sum() == 1
+    c = ctPLS(1, backend=NumpyBackend())
+    c.fit([x], y)
+    assert c.Xs_hasMiss == [True] and c.Xs_miss[0][2, 1, 1]
