@@ -246,7 +246,9 @@ def main():
                             "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
                             "max_abs_dT_vs_direct": float((sx.T - st.T).abs().max()),
                             "xcov_kernel": {"ms": xms, "alg_GB": xbytes / 1e9, "GBps": xbytes / xms / 1e6,
-                                            "f64_mfma_TFLOPs": 2.0 * rows * J * K * M / xms / 1e9}}
+                                            "f64_mfma_TFLOPs": 2.0 * rows * J * K * M / xms / 1e9,
+                                            "frac_of_f64_mfma_peak_78.6TF": 2.0 * rows * J * K * M / xms / 1e9 / 78.6,
+                                            "mfma_utilisation_pmc": "profiles/r01i_mfma_utilisation.json"}}
         del Xf, Yf
         # opt-in mixed precision of the S build (f32 MFMA, csrc/mixed.hip): reported, never the headline
         Xf, Yf = X.clone(), Y.clone()
