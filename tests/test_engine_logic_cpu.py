@@ -240,3 +240,51 @@ def test_miss_attributes_lazy():
     c = ctPLS(1, backend=NumpyBackend())
     c.fit([x], y)
     assert c.Xs_hasMiss == [True] and c.Xs_miss[0][2, 1, 1]
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    order = int(rng.integers(2, 6))
+    I = int(rng.integers(8, 25))
+    dims = tuple(int(rng.integers(2, 6)) for _ in range(order - 1))
+    M = int(rng.integers(1, 5))
+    X = rng.normal(size=(I,) + dims)
+    Y = rng.normal(size=(I, M)) if M > 1 or rng.random() < 0.5 else rng.normal(size=I)
+    if rng.random() < 0.4:
+        X[rng.random(X.shape) < 0.15] = np.nan
+    R = int(rng.integers(1, 4))
+    algorithm = "xcov" if rng.random() < 0.5 else "direct"
+    coupled = rng.random() < 0.35
+    return X, Y, R, algorithm, coupled, rng
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_problems_match_oracle(seed):
+    """Random orders (2-5), NaNs, 1-D or 2-D Y, tPLS or ctPLS (with an extra matrix block), both
+    algorithms: engine + NumPy backend == oracle (factors up to the paired sign, R2, iteration counts)."""
+    X, Y, R, algorithm, coupled, rng = _random_case(seed)
+    if coupled:
+        Xm = rng.normal(size=(X.shape[0], int(rng.integers(2, 7))))
+        m = ctPLS(R, backend=NumpyBackend(), algorithm=algorithm)
+        m.fit([X, Xm], Y)
+        fit = O.fit_ctpls([X, Xm], Y, R)
+        T, r2x = m.factor_T, m.R2Xs[0]
+        new = [X[::2].copy(), Xm[::2].copy()]
+        tr, want_tr = m.transform(new), O.transform(fit, new)
+    else:
+        m = tPLS(R, backend=NumpyBackend(), algorithm=algorithm)
+        m.fit(X, Y)
+        fit = O.fit_tpls(X, Y, R)
+        T, r2x = m.X_factors[0], m.R2X
+        tr, want_tr = m.transform(X[::2]), O.transform(fit, X[::2])
+    ok = ~np.isnan(fit.T).any()
+    if not ok:                       # an all-NaN row makes the reference itself produce NaN scores
+        assert np.isnan(T).any()
+        return
+    assert list(m.n_iter_) == list(fit.n_iter)
+    np.testing.assert_allclose(T, fit.T, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(m.Y_factors[1], fit.Q, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(m.coef_, fit.coef, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(r2x, fit.r2x[0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(tr, want_tr, rtol=1e-6, atol=1e-8)
