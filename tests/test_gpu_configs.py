@@ -172,3 +172,46 @@ def test_miss_x_synthetic_and_imputation(api):              # tests/test_missing
     m.fit(Xm, Y)
     from cmtf_pls_amd.util import calcR2X
     assert calcR2X(X[pos], m.X_reconstructed()[pos]) > 0.8
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    order = int(rng.integers(2, 6))
+    I = int(rng.integers(8, 25))
+    dims = tuple(int(rng.integers(2, 6)) for _ in range(order - 1))
+    M = int(rng.integers(1, 5))
+    X = rng.normal(size=(I,) + dims)
+    Y = rng.normal(size=(I, M)) if M > 1 or rng.random() < 0.5 else rng.normal(size=I)
+    if rng.random() < 0.4:
+        X[rng.random(X.shape) < 0.15] = np.nan
+    return X, Y, int(rng.integers(1, 4)), ("xcov" if rng.random() < 0.5 else "direct"), rng.random() < 0.35, rng
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_problems_match_oracle_on_gpu(api, seed):
+    """Random orders (2-5), NaNs, 1-D / 2-D Y, tPLS / ctPLS, both algorithms, on the HIP path."""
+    X, Y, R, algorithm, coupled, rng = _random_case(seed)
+    if coupled:
+        Xm = rng.normal(size=(X.shape[0], int(rng.integers(2, 7))))
+        m = api.ctPLS(R, algorithm=algorithm)
+        m.fit([X, Xm], Y)
+        fit = O.fit_ctpls([X, Xm], Y, R)
+        T, r2x = m.factor_T, m.R2Xs[0]
+        new = [X[::2].copy(), Xm[::2].copy()]
+        tr, want_tr = m.transform(new), O.transform(fit, new)
+    else:
+        m = api.tPLS(R, algorithm=algorithm)
+        m.fit(X, Y)
+        fit = O.fit_tpls(X, Y, R)
+        T, r2x = m.X_factors[0], m.R2X
+        tr, want_tr = m.transform(X[::2]), O.transform(fit, X[::2])
+    if np.isnan(fit.T).any():
+        assert np.isnan(T).any()
+        return
+    assert list(m.n_iter_) == list(fit.n_iter)
+    assert_allclose(T, fit.T, rtol=1e-6, atol=1e-8)
+    assert_allclose(m.Y_factors[1], fit.Q, rtol=1e-6, atol=1e-8)
+    assert_allclose(m.coef_, fit.coef, rtol=1e-5, atol=1e-8)
+    assert_allclose(r2x, fit.r2x[0], rtol=1e-6, atol=1e-9)
+    assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
+    assert_allclose(tr, want_tr, rtol=1e-6, atol=1e-8)
