@@ -189,6 +189,35 @@ def test_rank1_matches_lapack(be, shape):
     np.testing.assert_allclose(host(wB), fb, rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("shape", [(600, 640), (1024, 1024), (900, 40), (3, 5000)])
+def test_rank1_large(be, shape):
+    """The documented limit min(A, B) <= 1024 (64 x 64 tiles of trace / Frobenius partials) and wide
+    / tall shapes whose larger side is streamed in 256-column panels."""
+    A, B = shape
+    rng = np.random.default_rng(71)
+    Z = rng.normal(size=shape) + 6.0 * np.outer(rng.normal(size=A), rng.normal(size=B))
+    wA, wB, info = be.empty(A), be.empty(B), be.zeros(2)
+    be.rank1(dev(Z.ravel()), A, B, wA, wB, info=info)
+    u, v, S = _svd_pair(Z)
+    np.testing.assert_allclose(host(wA), u, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(host(wB), v, rtol=0, atol=1e-9)
+    assert host(info)[0] == 1.0
+
+
+def test_rank1_tensor_larger_modes(be):
+    rng = np.random.default_rng(72)
+    dims = (40, 30, 20)
+    core = rng.normal(size=dims[0])
+    for d in dims[1:]:
+        core = np.multiply.outer(core, rng.normal(size=d))
+    Z = rng.normal(size=dims) + 3.0 * core
+    fac = be.zeros(3, 40)
+    be.rank1_tensor(dev(Z.ravel()), dims, 1e-8, fac)
+    want = O.rank1_factors(Z, 1e-8)
+    for m, w in enumerate(want):
+        np.testing.assert_allclose(host(fac)[m, : dims[m]], w, rtol=1e-7, atol=1e-9)
+
+
 def test_rank1_close_singular_values_and_zero_rows(be):
     rng = np.random.default_rng(12)
     A, B = 40, 30
