@@ -474,7 +474,6 @@ class FitRun:
                 be.rowdot(self.Y, self.q, u_new, None)                           # tpls.py:102
                 if it > 0:
                     be.quadform(self.Gy, self.q, self.q_prev, self.status[0:1])  # tpls.py:103
-                self.q_prev.copy_(self.q)
             else:
                 be.rowdot(self.Y, self.q, u_new, u if it > 0 else None, du2=self.status[0:1])   # tpls.py:102-103
 
@@ -502,7 +501,9 @@ class FitRun:
             if not self._update_budgets(host):
                 break
             first = False
-        self._parity ^= 1
+        if sharded:
+            self.q_prev.copy_(self.q)            # only after the accepted attempt (a retry must compare against
+        self._parity ^= 1                        # the previous ITERATION's q, not the rejected attempt's)
         return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))          # tpls.py:103
 
     def finish_component(self, a: int) -> None:

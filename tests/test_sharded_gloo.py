@@ -82,3 +82,56 @@ def test_world2_matches_oracle(case):
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def _retry_worker(rank, world, port, ret):
+    """Forces the rank-1 budget retry in every iteration (sharded direct path): the rejected
+    attempt's q must not leak into the convergence norm."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from cmtf_pls_amd.engine import Comm, NipalsEngine
+        from numpy_backend import NumpyBackend
+
+        class Flaky(NumpyBackend):
+            def rank1(self, Z, A, B, wA, wB, info=None, n_squarings=None):
+                super().rank1(Z, A, B, wA, wB, info=info, n_squarings=n_squarings)
+                if n_squarings is not None and n_squarings < self.rank1_squarings:
+                    wA.copy_(torch.roll(wA, 1))          # a wrong vector + "not converged"
+                    info[0] = 0.0
+
+        x, y, _ = O.import_synthetic((60, 8, 6), 3, 3, error=0.1, seed=21)
+        rows = slice(rank * 30, (rank + 1) * 30)
+        eng = NipalsEngine(Flaky(), Comm())
+        X = torch.from_numpy(x[rows].copy())
+        Y = torch.from_numpy(y[rows].copy())
+        run = eng.begin([X], Y, 3, coupled=False)
+        for a in range(3):
+            run.start_component(a)
+            for it in range(100):
+                run.sq_budget = [5]                      # too small on purpose: every iteration retries
+                du = run.iterate(it)
+                if du is not None and du < 1e-8:
+                    break
+            run.finish_component(a)
+        st = run.result()
+        fit = O.fit_tpls(x, y, 3)
+        assert list(st.n_iter) == list(fit.n_iter)
+        np.testing.assert_allclose(st.T.numpy(), fit.T[rows], rtol=1e-6, atol=1e-8)
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc() + repr(e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank1_budget_retry_sharded():
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_retry_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
