@@ -38,7 +38,7 @@ class ctPLS(_EstimatorBase):
         self.Xs_dim = [X.ndim for X in Xs]
         self.Xs_shape = [tuple(X.shape) for X in Xs]
         self.Y_shape = tuple(Y2.shape)
-        Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev) for X in Xs]
+        Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=self._copy_X) for X in Xs]
         Yd = to_device_copy(Y2, torch.float64, dev)
         st = eng.fit(Xd, Yd, self.n_components, tol, max_iter, coupled=True, verbose=verbose, algorithm=self._algorithm,
                      use_graphs=self._graphs, mixed=self._mixed)

@@ -32,9 +32,13 @@ def _as_torch_dtype(dtype, like) -> torch.dtype:
     return {"float32": torch.float32, "f32": torch.float32, "float64": torch.float64, "f64": torch.float64}[name]
 
 
-def to_device_copy(X, dtype: torch.dtype, device) -> torch.Tensor:
-    """A fresh contiguous device tensor of X (inputs are never modified, tpls.py:74,128,151)."""
+def to_device_copy(X, dtype: torch.dtype, device, copy: bool = True) -> torch.Tensor:
+    """A fresh contiguous device tensor of X (inputs are never modified, tpls.py:74,128,151).
+    copy=False (opt-in ``copy_X=False``): a device tensor that already has the right type is used in
+    place and is centred / deflated by the fit."""
     if isinstance(X, torch.Tensor):
+        if not copy and X.is_contiguous() and X.dtype == dtype and X.device == torch.device(device):
+            return X
         out = X.to(device=device, dtype=dtype, copy=True)
     else:
         out = torch.from_numpy(np.ascontiguousarray(X)).to(device=device, dtype=dtype, copy=True)
@@ -43,7 +47,7 @@ def to_device_copy(X, dtype: torch.dtype, device) -> torch.Tensor:
 
 class _EstimatorBase(Mapping):
     def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None,
-                 algorithm: str = "direct", graphs: bool = False, matrix_precision: str = "f64"):
+                 algorithm: str = "direct", graphs: bool = False, matrix_precision: str = "f64", copy_X: bool = True):
         super().__init__()
         self.n_components = n_components
         self._algorithm = algorithm
@@ -51,6 +55,7 @@ class _EstimatorBase(Mapping):
         if matrix_precision not in ("f64", "f32"):
             raise ValueError("matrix_precision must be 'f64' or 'f32'")
         self._mixed = matrix_precision == "f32"   # f32-MFMA S build / MTTKRP for f32-stored X (opt-in)
+        self._copy_X = copy_X                     # False: a device-resident X is fitted in place (and destroyed)
         self._dtype = dtype
         self._device = device
         self._comm = comm
@@ -117,7 +122,7 @@ class tPLS(_EstimatorBase):
         self.X_dim = X.ndim
         self.X_shape = tuple(X.shape)
         self.Y_shape = tuple(Y2.shape)
-        Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev)
+        Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=self._copy_X)
         Yd = to_device_copy(Y2, torch.float64, dev)
         st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose, algorithm=self._algorithm,
                      use_graphs=self._graphs, mixed=self._mixed)

@@ -449,3 +449,15 @@ def test_torch_device_inputs_and_q2y(api):
         pred[i] = O.predict(O.fit_tpls(x[keep], y[keep], 2), x[i:i + 1])[0]
     want = 1 - ((pred - y) ** 2).sum() / (y ** 2).sum()
     assert_allclose(get_q2y(mh), want, rtol=1e-6)
+
+
+def test_copy_x_false_fits_in_place(api):
+    import torch
+    x, y, _ = O.import_synthetic((128, 8, 8), 3, 2, error=0.1, seed=4)
+    Xd = torch.from_numpy(x).cuda()
+    ref = api.tPLS(2)
+    ref.fit(x, y)
+    m = api.tPLS(2, copy_X=False)
+    m.fit(Xd, y)
+    assert_allclose(m.X_factors[0], ref.X_factors[0], rtol=1e-12, atol=1e-12)
+    assert not torch.equal(Xd.cpu(), torch.from_numpy(x))        # the caller's tensor was centred and deflated
