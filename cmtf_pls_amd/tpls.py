@@ -6,6 +6,8 @@ Same constructor, ``fit / predict / transform / X_reconstructed / copy``, Mappin
 Opt-in extras (defaults reproduce the reference): ``dtype`` (storage type of X on the GPU:
 "float32" | "float64" | None = follow the input), ``algorithm`` ("direct" = the reference's loop,
 "xcov" = the same iteration through the cross-covariance S = X_(0)^T Y, one X read per component),
+``graphs`` (replay each iteration as a HIP graph), ``matrix_precision`` ("f64" | "f32": the opt-in
+f32-MFMA form of the two matrix-core kernels), ``copy_X`` (False: fit a device-resident X in place),
 ``device``, ``comm`` (sample-mode sharding: each
 rank passes its own rows), ``n_iter_`` (inner iterations executed per component) and
 ``original_X / original_Y`` (which the reference's validate.get_q2y reads, validate.py:18-21).
