@@ -173,12 +173,17 @@ def main():
     # (2) the same K iterations with the launch sequence replayed as a HIP graph (the headline when
     #     capture works: identical kernels, ~1 host call per iteration instead of ~20 launches)
     if args.graphs:
-        run.use_graphs = True
-        for _ in range(max(args.warmup, 4)):       # captures both u-buffer parities
-            run.iterate(state["it"])
-            state["it"] += 1
-        if run.use_graphs:
-            elapsed = timed(args.steps, events=False)
+        try:
+            run.use_graphs = True
+            for _ in range(max(args.warmup, 4)):   # captures both u-buffer parities
+                run.iterate(state["it"])
+                state["it"] += 1
+            if run.use_graphs:
+                elapsed = timed(args.steps, events=False)
+        except Exception as e:                     # keep the eager figure rather than lose the run
+            run.use_graphs = False
+            run._graph_error = repr(e)
+            elapsed = eager_elapsed
     graphs_used, graph_error = run.use_graphs, run._graph_error
     run.finish_component(0)                        # exercises the deflation sweep once (timed below by events)
 
