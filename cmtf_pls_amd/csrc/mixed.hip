@@ -19,9 +19,21 @@ namespace cmtfpls {
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
+#ifndef CMTFPLS_MIXED_UN
+#define CMTFPLS_MIXED_UN 4
+#endif
+#ifndef CMTFPLS_MIXED_FAST
+#define CMTFPLS_MIXED_FAST 1
+#endif
+#ifndef CMTFPLS_MIXED_UN_WIDE
+#define CMTFPLS_MIXED_UN_WIDE 4
+#endif
+
 void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st);
 
-template <bool MASKED, bool VEC, int MT>
+// FAST: every tile is interior (P % 256 == 0, M % 16 == 0, row blocks a multiple of 8 * UN rows): no
+// clamps and no selects around the MFMAs.
+template <bool MASKED, bool VEC, int MT, bool FAST>
 __global__ __launch_bounds__(256) void xcov_mixed_kernel(const float* __restrict__ X, int64_t I, int64_t P,
                                                         const double* __restrict__ Y, int ldy, int M,
                                                         double* __restrict__ part, int rows_per_block) {
@@ -47,14 +59,17 @@ __global__ __launch_bounds__(256) void xcov_mixed_kernel(const float* __restrict
   int ycol[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) { mok[mt] = (mt * 16 + nn) < M; ycol[mt] = mok[mt] ? mt * 16 + nn : M - 1; }
-  constexpr int UN = 4;
+  // prefetch depth: two register stages of UN loads each (fewer at M > 16, where the accumulators
+  // already take 96 registers and occupancy is what hides the HBM latency)
+  constexpr int UN = (MT >= 2) ? CMTFPLS_MIXED_UN_WIDE : CMTFPLS_MIXED_UN;
+  constexpr int FLUSH_TRIPS = 64 / (8 * UN);     // f32 chains of 64 rows
   const int64_t cc = (c < P) ? c : (VEC ? P - 4 : P - 1);
 
-  auto load_stage = [&](XV (&x)[UN], float (&a)[UN][MT], int64_t r) {
+  auto load_stage = [&](XV (&x)[UN], double (&a)[UN][MT], int64_t r) {
 #pragma unroll
     for (int s = 0; s < UN; ++s) {
       const int64_t row = r + 4 * s + kq;
-      const int64_t rowc = (row < r1) ? row : r1 - 1;
+      const int64_t rowc = (FAST || row < r1) ? row : r1 - 1;
       if (VEC) {
         x[s] = ld_stream(reinterpret_cast<const XV*>(X + rowc * P + cc));
       } else {
@@ -62,21 +77,25 @@ __global__ __launch_bounds__(256) void xcov_mixed_kernel(const float* __restrict
         for (int e = 0; e < 4; ++e) x[s].e[e] = X[rowc * P + ((cc + e < P) ? cc + e : P - 1)];
       }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[s][mt] = (float)Y[rowc * ldy + ycol[mt]];
+      for (int mt = 0; mt < MT; ++mt) a[s][mt] = Y[rowc * ldy + ycol[mt]];   // rounded to f32 at use, not here:
+                                                                             // a convert here would wait on the load
     }
   };
-  auto mma_stage = [&](const XV (&x)[UN], const float (&a)[UN][MT], int64_t r) {
+  auto mma_stage = [&](const XV (&x)[UN], const double (&a)[UN][MT], int64_t r) {
 #pragma unroll
     for (int s = 0; s < UN; ++s) {
-      const bool rok = (r + 4 * s + kq) < r1;
+      const bool rok = FAST || (r + 4 * s + kq) < r1;
+      float af[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = (FAST || (rok && mok[mt])) ? (float)a[s][mt] : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float xv = x[s].e[e];
         if (MASKED) xv = (xv == xv) ? xv : 0.f;
-        const float b = (rok && c + e < P) ? xv : 0.f;
+        const float b = (FAST || (rok && c + e < P)) ? xv : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc32[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32((rok && mok[mt]) ? a[s][mt] : 0.f, b, acc32[mt][e], 0, 0, 0);
+          acc32[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], b, acc32[mt][e], 0, 0, 0);
       }
     }
   };
@@ -92,15 +111,23 @@ __global__ __launch_bounds__(256) void xcov_mixed_kernel(const float* __restrict
   };
 
   XV xa[UN], xb[UN];
-  float aa[UN][MT], ab[UN][MT];
+  double aa[UN][MT], ab[UN][MT];
   load_stage(xa, aa, r0);
   int trip = 0;
   for (int64_t r = r0; r < r1; r += 8 * UN, ++trip) {
+    // the barriers pin "issue the whole next stage, then multiply the current one": left alone, the
+    // scheduler sinks the loads next to their first use (vmcnt(0) straight after the load) when
+    // registers are tight (M > 16), which serialises HBM latency with the matrix pipe
     load_stage(xb, ab, r + 4 * UN);
+    __builtin_amdgcn_sched_barrier(0);
     mma_stage(xa, aa, r);
-    load_stage(xa, aa, r + 8 * UN);
+    __builtin_amdgcn_sched_barrier(0);
+    // FAST has no clamp: the look-ahead of the last trip must stay inside this block's rows
+    load_stage(xa, aa, (FAST && r + 8 * UN >= r1) ? r : r + 8 * UN);
+    __builtin_amdgcn_sched_barrier(0);
     mma_stage(xb, ab, r + 4 * UN);
-    if (trip & 1) flush();                 // f32 chains of 64 rows
+    __builtin_amdgcn_sched_barrier(0);
+    if (trip % FLUSH_TRIPS == FLUSH_TRIPS - 1) flush();
   }
   flush();
 #pragma unroll
@@ -216,10 +243,13 @@ int cmtfpls_xcov_f32_mixed(const float* X, int64_t I, int64_t P, const double* Y
   const int mt = (M + 15) / 16;
   double* part = static_cast<double*>(ws);
   const dim3 grid(p.col_tiles, p.row_blocks), block(256);
-#define XL(MSK, VC, MTT) hipLaunchKernelGGL((xcov_mixed_kernel<MSK, VC, MTT>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block)
-#define XM(MSK, VC) do { if (mt == 1) XL(MSK, VC, 1); else if (mt == 2) XL(MSK, VC, 2); else XL(MSK, VC, 4); } while (0)
-  if (masked) { if (vec) XM(true, true); else XM(true, false); }
-  else        { if (vec) XM(false, true); else XM(false, false); }
+  constexpr int kMaxUn = (CMTFPLS_MIXED_UN > CMTFPLS_MIXED_UN_WIDE) ? CMTFPLS_MIXED_UN : CMTFPLS_MIXED_UN_WIDE;
+  const bool fast = CMTFPLS_MIXED_FAST && vec && (P % 256 == 0) && (M % 16 == 0) && (M / 16 != 3) && (I % p.rows_per_block == 0) &&
+                    (p.rows_per_block % (8 * kMaxUn) == 0);
+#define XL(MSK, VC, MTT, FS) hipLaunchKernelGGL((xcov_mixed_kernel<MSK, VC, MTT, FS>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block)
+#define XM(MSK, VC, FS) do { if (mt == 1) XL(MSK, VC, 1, FS); else if (mt == 2) XL(MSK, VC, 2, FS); else XL(MSK, VC, 4, FS); } while (0)
+  if (masked) { if (fast) XM(true, true, true); else if (vec) XM(true, true, false); else XM(true, false, false); }
+  else        { if (fast) XM(false, true, true); else if (vec) XM(false, true, false); else XM(false, false, false); }
 #undef XM
 #undef XL
   launch_reduce_rows(part, p.row_blocks, (int64_t)M * P, S, st);

@@ -368,8 +368,10 @@ __global__ __launch_bounds__(kSweepThreads) void center_kernel(
 // ------------------------------------------------------------------------------------------
 // KC ("k constant"): the workgroup stride is a multiple of B, so every vector a lane owns has the
 // same k = c % B (its wB entries live in registers for the whole kernel) and j advances by a uniform
-// stride / B.  This is the shape of every power-of-two benchmark configuration and keeps the
-// 1024-thread variant (a 256 KB row in registers) inside 128 VGPRs without spilling.
+// stride / B.  This is the shape of every power-of-two benchmark configuration.
+// 1024-thread variant (rows up to 256 KB): only NR = NV/2 vectors of a lane stay in registers; the
+// other NL = NV/2 are parked in LDS between the phases (128 KB of the CU's 160 KB; one workgroup per
+// CU either way), which keeps the kernel inside the 128-VGPR budget of 16 waves/CU without spilling.
 template <typename T, bool MASKED, bool VEC, int NV, int MAXT, int MODE>
 __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
     T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ wA,
@@ -377,17 +379,23 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
     double* __restrict__ ssq_part) {
   constexpr bool KC = MODE >= 1;     // stride % B == 0
   constexpr bool FULL = MODE == 2;   // and the workgroup covers the row exactly: no column guards
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  using VT = Pack<T, V>;
+  constexpr int NL = (MAXT > 256) ? NV / 2 : 0;   // vectors per lane parked in LDS
+  constexpr int NR = NV - NL;                     // vectors per lane held in registers
+  constexpr int G = 4;                            // parked vectors are streamed G loads at a time
+  static_assert(NL % G == 0, "parked vectors come in groups of G");
   extern __shared__ double lds[];
   __shared__ double red[2][16];
   __shared__ double red2[16];
+  __shared__ VT park[NL > 0 ? NL * MAXT : 1];
   double* sA = lds;
   double* sB = lds + ((A + 1) & ~1);
   stage_loadings(sA, sB, wA, wB, A, B);
-  constexpr int V = VEC ? VecOf<T>::N : 1;
-  using VT = Pack<T, V>;
   // a row is < 2^31 elements (guarded on the host): 32-bit element offsets from a uniform row base
   const unsigned P = (unsigned)A * (unsigned)B;
-  const unsigned stride = blockDim.x * V;
+  // the 1024-thread variant is always launched with exactly MAXT threads: a compile-time stride
+  const unsigned stride = (MAXT > 256 ? (unsigned)MAXT : blockDim.x) * V;
   const unsigned c0 = threadIdx.x * V;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   const KronWalk w0(c0, stride, B);   // row independent; re-walked per phase (cheaper than 2*NV registers)
@@ -398,16 +406,22 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
   double ssq = 0.0;
   int parity = 0;
   for (int64_t row = blockIdx.x; row < I; row += gridDim.x, parity ^= 1) {
-    T* __restrict__ xr = X + row * (int64_t)P;
-    VT x[NV];
+    // scalar row base (opaque to loop strength reduction, which otherwise keeps one 64-bit running
+    // address per vector in VGPRs): every access is SGPR base + one shared VGPR offset
+    const uint64_t rb = reinterpret_cast<uint64_t>(X + row * (int64_t)P);
+    // (the builtin returns int: without the uint32_t casts the low half would be sign-extended)
+    const uint32_t rb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rb >> 32));
+    const uint32_t rb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rb);
+    T* __restrict__ xr = reinterpret_cast<T*>(((uint64_t)rb_hi << 32) | (uint64_t)rb_lo);
+    VT x[NR];
 #pragma unroll
-    for (int n = 0; n < NV; ++n)
+    for (int n = 0; n < NR; ++n)
       if (FULL || c0 + n * stride < P) x[n] = ld_stream(reinterpret_cast<const VT*>((xr + (int64_t)n * stride) + c0));
     double acc = 0.0;
     {
       KronWalk w = w0;
 #pragma unroll
-      for (int n = 0; n < NV; ++n) {
+      for (int n = 0; n < NR; ++n) {
         if (KC) {
           int jn = w0.j + n * dj;
           asm volatile("" : "+v"(jn));             // keep the sA read inside the row loop (no hoisting into 2*NV registers)
@@ -417,6 +431,29 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
           w.next();
         }
         if (NV > 4) __builtin_amdgcn_sched_barrier(0);   // keep live temporaries low: the row owns the VGPRs
+      }
+      // parked half: G loads in flight, scored, then written to this lane's LDS slots
+#pragma unroll
+      for (int n0 = NR; n0 < NV; n0 += G) {
+        VT tmp[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (FULL || c0 + (n0 + g) * stride < P)
+            tmp[g] = ld_stream(reinterpret_cast<const VT*>((xr + (int64_t)(n0 + g) * stride) + c0));
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int n = n0 + g;
+          if (KC) {
+            int jn = w0.j + n * dj;
+            asm volatile("" : "+v"(jn));
+            if (FULL || c0 + n * stride < P) acc = fma(sA[jn], dot_pack<T, V, MASKED>(tmp[g], wbv), acc);
+          } else {
+            if (c0 + n * stride < P) acc = fma(sA[w.j], dot_pack<T, V, MASKED>(tmp[g], sB + w.k), acc);
+            w.next();
+          }
+          if (FULL || c0 + n * stride < P) park[(n - NR) * MAXT + threadIdx.x] = tmp[g];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     acc = wave_sum(acc);
@@ -428,9 +465,9 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
     if (threadIdx.x == 0) t[row] = ti;
     if (sizeof(T) == 4) {
       // make the stored row opaque here: otherwise the f64 conversions of phase 1 are kept alive
-      // across the barrier for reuse (2 extra VGPRs per element: spills at NV = 16)
+      // across the barrier for reuse (2 extra VGPRs per element)
 #pragma unroll
-      for (int n = 0; n < NV; ++n)
+      for (int n = 0; n < NR; ++n)
 #pragma unroll
         for (int e = 0; e < V; ++e) asm volatile("" : "+v"(x[n].e[e]));
     }
@@ -441,24 +478,23 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
         int jn = KC ? w0.j + n * dj : w.j;
         if (KC) asm volatile("" : "+v"(jn));
         if (FULL || c0 + n * stride < P) {
+          VT xv;
+          if (n < NR) xv = x[n < NR ? n : 0];
+          else xv = park[(n - NR) * MAXT + threadIdx.x];   // this lane's own slot: no barrier needed
           const double tw = ti * sA[jn];
 #pragma unroll
           for (int e = 0; e < V; ++e) {
-            const T nv = (T)fma(-tw, KC ? wbv[e] : sB[w.k + e], (double)x[n].e[e]);
-            x[n].e[e] = nv;
+            const T nv = (T)fma(-tw, KC ? wbv[e] : sB[w.k + e], (double)xv.e[e]);
+            xv.e[e] = nv;
             const double d = (nv == nv) ? (double)nv : 0.0;
             ssq = fma(d, d, ssq);
           }
-          st_stream(reinterpret_cast<VT*>((xr + (int64_t)n * stride) + c0), x[n]);
+          st_stream(reinterpret_cast<VT*>((xr + (int64_t)n * stride) + c0), xv);
         }
         if (!KC) w.next();
         if (NV > 4) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // 1024-thread variant: the row already fills half of the 128-VGPR budget; stop the compiler from
-    // hoisting the next row's loads above this row's stores (it does so for the 256-thread variant,
-    // which has the registers for two rows in flight)
-    if (MAXT > 256) asm volatile("" ::: "memory");
   }
   if (ssq_part) {
     const double s = block_sum(ssq, red2);

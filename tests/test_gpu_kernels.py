@@ -138,7 +138,9 @@ def test_deflate(be, shape, dt):
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 @pytest.mark.parametrize("masked", [False, True])
-@pytest.mark.parametrize("shape", SHAPES + [(9, 64, 64), (5, 256, 256), (3, 200, 75)])
+# the last four take the 1024-thread variant (half of the row parked in LDS): exact cover, stride % B == 0
+# with a ragged tail, the general vector walk, and the scalar walk
+@pytest.mark.parametrize("shape", SHAPES + [(9, 64, 64), (3, 200, 75), (5, 256, 256), (4, 100, 256), (4, 150, 200), (3, 101, 99)])
 def test_score_deflate_fused(be, shape, dt, masked):
     I, A, B = shape
     x = make_x(shape, dt, nan_frac=0.2 if masked else 0.0, seed=9)
@@ -151,7 +153,7 @@ def test_score_deflate_fused(be, shape, dt, masked):
     t = be.empty(I)
     ssq = be.score_deflate(X, A, B, dev(wa), dev(wb), rowcnt, t)
     if ssq is None:
-        assert (dt == "f64" and A * B > 32768)
+        assert A * B > 1024 * 16 * (2 if dt == "f64" else 4 if B % 4 == 0 else 1)
         return
     x3 = x.reshape(I, A, B)
     t_want = O.masked_score(x3, [wa, wb]) if masked else O.score_contract(x3, [wa, wb])
@@ -389,3 +391,47 @@ def test_mttkrp_mfma(be, shape, R, dt):
     out = be.mttkrp(dev(x, TDT[dt]), A, B, dev(WA), dev(WB), be.empty(I, R))
     W = (WA[:, None, :] * WB[None, :, :]).reshape(A * B, R)
     np.testing.assert_allclose(host(out), x @ W, rtol=1e-11, atol=1e-10)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (8, 256, 256)])
+@pytest.mark.parametrize("where", ["bit31", "wrap32"])
+def test_sweeps_do_not_depend_on_address_bits(be, shape, where):
+    """Every X sweep gives bit-identical results when X sits where the low 32 address bits flip sign
+    ("bit31": X straddles an address with low word 0x80000000) or carry ("wrap32": X straddles a
+    multiple of 2^32).  Regression: a scalar row base rebuilt from two 32-bit halves once sign-extended
+    its low half, which faulted for whichever allocations had bit 31 set."""
+    I, A, B = shape
+    P = A * B
+    nbytes = I * P * 4
+    pool = torch.empty((1 << 32) + (1 << 29), dtype=torch.uint8, device="cuda:0")      # contains a 2^32 boundary
+    base = pool.data_ptr()
+    target = (1 << 31) if where == "bit31" else 0
+    # first address >= base whose low word is `target`, then step back half of X so that X straddles it
+    off = (target - base) % (1 << 32) - (nbytes // 2 // 256) * 256
+    if off < 0:
+        off += 1 << 32
+    assert 0 <= off and off + nbytes <= pool.numel()
+    Xs = pool[off:off + nbytes].view(torch.float32).view(I, P)
+    lo, hi = Xs.data_ptr(), Xs.data_ptr() + nbytes - 1
+    assert (lo >> 31) != (hi >> 31)                                                      # the boundary is inside X
+    x = make_x(shape, "f32", seed=77)
+    rng = np.random.default_rng(78)
+    wa, wb = rng.normal(size=A), rng.normal(size=B)
+    wa, wb = dev(wa / np.linalg.norm(wa)), dev(wb / np.linalg.norm(wb))
+    u = dev(rng.normal(size=I))
+    Xn = dev(x, torch.float32)                                                           # an ordinary allocation
+    Xs.copy_(Xn)
+    outs = []
+    for X in (Xn, Xs):
+        Z = be.mode0_contract(X, u, False).clone()
+        t1 = be.empty(I)
+        be.score(X, A, B, wa, wb, None, t1)
+        t2 = be.empty(I)
+        ssq = be.score_deflate(X, A, B, wa, wb, None, t2)
+        assert ssq is not None
+        ssq = ssq.clone()
+        ssq2 = be.deflate(X, A, B, t1, wa, wb).clone()
+        outs.append((Z, t1, t2, ssq, ssq2, X.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(host(outs[0][1]), O.score_contract(x.reshape(I, A, B), [host(wa), host(wb)]), **RT)
