@@ -40,6 +40,10 @@ __device__ __forceinline__ double pow2_scale_from_trace(const double* parts, int
 
 // C = s^2 * M M^T for row-major M (n x k, leading dim ld); s is the power-of-two scale derived from
 // the trace of the input (step >= 1) or 1 (step 0, the Gram matrix of Z itself).
+// A step is a chain of memory latencies (the previous step's output lives in another XCD's L2), so the
+// kernel issues the loads of its two 16 x 256 panels first, into registers, and only then reads the
+// control block (traces, Frobenius partials) that decides the scale and the early exit: one latency per
+// step instead of three, and no load waits behind another.
 __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* __restrict__ M, int n, int k, int ld,
                                                                 double* __restrict__ C, Rank1Ctl* __restrict__ ctl,
                                                                 int step, int out_buf) {
@@ -47,17 +51,57 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   __shared__ double diag[kTile];
   __shared__ double s_scale;
   __shared__ int s_done;
+  __shared__ double fsum[4];
+  __shared__ double tr_s[kMaxTiles];
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTile + tx;
   const int nt = (n + kTile - 1) / kTile;
-  __shared__ double fsum[4];
+  const int i0 = blockIdx.y * kTile, j0 = blockIdx.x * kTile;
+
+  // (1) first k-chunk of both panels: thread (ty, tx) owns row ty, columns tx + 16 u.  Loads are
+  // unconditional (clamped address, select afterwards) so that all of them are in flight together.
+  constexpr int PU = kPanelK / kTile / 2;            // 8 loads per panel per batch, two batches
+  const int kc0 = (k < kPanelK) ? k : kPanelK;
+  const bool ra = (i0 + ty) < n, rb = (j0 + ty) < n;
+  const double* __restrict__ rowa = M + (int64_t)(ra ? i0 + ty : 0) * ld;
+  const double* __restrict__ rowb = M + (int64_t)(rb ? j0 + ty : 0) * ld;
+  double pa[2][PU], pb[2][PU];
+#pragma unroll
+  for (int u = 0; u < PU; ++u) {
+    const int c = tx + kTile * u;
+    const int cc = (c < kc0) ? c : 0;
+    pa[0][u] = rowa[cc];                             // masked when written to LDS, not here: a select
+    pb[0][u] = rowb[cc];                             // next to the load becomes a branch around it
+  }
+  const bool wide = kc0 > kTile * PU;                // uniform: a second batch of columns exists
+  if (wide) {
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int c = tx + kTile * (PU + u);
+      const int cc = (c < kc0) ? c : 0;
+      pa[1][u] = rowa[cc];
+      pb[1][u] = rowb[cc];
+    }
+  }
+
+  // (2) control: scale from the input's trace, early exit once the input is numerically rank one.
+  // The control words are vector loads issued right behind the panel loads (same single wait).
   double fro_in = 0.0;
   if (step >= 1) {
-    // |G_{s-1}|_F^2 from the per-tile sums the previous step left (fixed order: bit-reproducible)
+    // the flag's address is laundered into a VGPR so that this is a vector load in the same batch as
+    // the others (as a scalar load the compiler issues it after the wait: a second latency)
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    const int done_in = (&ctl->done)[zero];
     const double* fp = ctl->fro[(step - 1) & 1];
-    double f = 0.0;
-    for (int i = tid; i < nt * nt; i += kTile * kTile) f += fp[i];
+    const double trv = ctl->trace[step - 1][(tid < nt) ? tid : 0];
+    // |G_{s-1}|_F^2 from the per-tile sums the previous step left (fixed order: bit-reproducible)
+    double f = fp[(tid < nt * nt) ? tid : 0];
+    if (tid < nt) tr_s[tid] = trv;
+    if (tid >= nt * nt) f = 0.0;
+    for (int i = tid + kTile * kTile; i < nt * nt; i += kTile * kTile) f += fp[i];
     f = wave_sum(f);
     if ((tid & 63) == 0) fsum[tid >> 6] = f;
+    if (tid == 0) s_done = done_in;
     __syncthreads();
     fro_in = ((fsum[0] + fsum[1]) + fsum[2]) + fsum[3];
   }
@@ -67,11 +111,11 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
     if (step == 0) {
       if (blockIdx.x == 0 && blockIdx.y == 0) { ctl->done = 0; ctl->final_buf = -1; ctl->steps_used = 0; }
     } else {
-      done = ctl->done;
+      done = s_done;
       if (!done) {
         // G_s = (sc_{s-1} G_{s-1})^2 with sc_{s-1} the power-of-two scale of tr(G_{s-1}).
         double tr1;
-        scale = pow2_scale_from_trace(ctl->trace[step - 1], nt, &tr1);
+        scale = pow2_scale_from_trace(tr_s, nt, &tr1);
         // rho = tr(G^2) / tr(G)^2 of the INPUT G_{s-1} is 1 - 2*(lambda_2/lambda_1) to first order:
         // at 1 - 1e-13 the input is rank one to 5e-14 and is taken as the result (its dominant column
         // then still goes through one exact pass with Z in the finish kernels).
@@ -89,18 +133,33 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   __syncthreads();
   if (s_done) return;
   const double scale = s_scale;
-  const int i0 = blockIdx.y * kTile, j0 = blockIdx.x * kTile;
+
+  // (3) the product, k-chunk by k-chunk (one chunk whenever k <= 256: every squaring of the
+  // benchmark shapes); the summation order over k is ascending, as a plain dot product
   double acc = 0.0;
   for (int kk = 0; kk < k; kk += kPanelK) {
     const int kc = (k - kk < kPanelK) ? k - kk : kPanelK;
     const int ldp = kc + 1;
     double* As = panel;
     double* Bs = panel + kTile * ldp;
-    // stage both 16 x kc panels: consecutive threads read consecutive k (coalesced), all loads in flight
-    for (int idx = tid; idx < kTile * kc; idx += kTile * kTile) {
-      const int r = idx / kc, c = idx - r * kc;
-      As[r * ldp + c] = (i0 + r < n) ? M[(int64_t)(i0 + r) * ld + kk + c] : 0.0;
-      Bs[r * ldp + c] = (j0 + r < n) ? M[(int64_t)(j0 + r) * ld + kk + c] : 0.0;
+    if (kk == 0) {
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int c = tx + kTile * u;
+        if (c < kc) { As[ty * ldp + c] = ra ? pa[0][u] : 0.0; Bs[ty * ldp + c] = rb ? pb[0][u] : 0.0; }
+      }
+      if (wide) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+          const int c = tx + kTile * (PU + u);
+          if (c < kc) { As[ty * ldp + c] = ra ? pa[1][u] : 0.0; Bs[ty * ldp + c] = rb ? pb[1][u] : 0.0; }
+        }
+      }
+    } else {
+      for (int c = tx; c < kc; c += kTile) {
+        As[ty * ldp + c] = ra ? rowa[kk + c] : 0.0;
+        Bs[ty * ldp + c] = rb ? rowb[kk + c] : 0.0;
+      }
     }
     __syncthreads();
     const double* ar = As + ty * ldp;
@@ -116,8 +175,7 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
     // this tile's contribution to |G_s|_F^2
     double sq = inside ? acc * acc : 0.0;
     sq = wave_sum(sq);
-    __syncthreads();                       // fsum is free again (read before the first barrier above)
-    if ((tid & 63) == 0) fsum[tid >> 6] = sq;
+    if ((tid & 63) == 0) fsum[tid >> 6] = sq;   // fsum is free: its readers passed two barriers since
     __syncthreads();
     if (tid == 0) ctl->fro[step & 1][blockIdx.y * nt + blockIdx.x] = ((fsum[0] + fsum[1]) + fsum[2]) + fsum[3];
   }
@@ -210,11 +268,12 @@ __global__ __launch_bounds__(256) void rank1_x_kernel(const double* __restrict__
   if (lane == 0) x[j] = s;
 }
 
-// F3: normalise x and y, apply the sign rule, write wA / wB / sigma / info
-__global__ __launch_bounds__(1024) void rank1_final_kernel(const double* __restrict__ x, const double* __restrict__ y,
-                                                          int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
-                                                          double* __restrict__ wA, double* __restrict__ wB,
-                                                          double* __restrict__ sigma, double* __restrict__ info) {
+// F3: normalise x and y, apply the sign rule, write wA / wB / sigma / info   (1024 threads; x, y may
+// live in global memory or in LDS)
+__device__ __forceinline__ void rank1_final_body(const double* x, const double* y,
+                                                 int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
+                                                 double* __restrict__ wA, double* __restrict__ wB,
+                                                 double* __restrict__ sigma, double* __restrict__ info) {
   __shared__ double red[2][16];
   __shared__ double bestv[16];
   __shared__ int besti[16];
@@ -254,6 +313,13 @@ __global__ __launch_bounds__(1024) void rank1_final_kernel(const double* __restr
     if (sigma) sigma[0] = nx / ny;
     if (info) { info[0] = ctl->done ? 1.0 : 0.0; info[1] = (double)ctl->steps_used; }
   }
+}
+
+__global__ __launch_bounds__(1024) void rank1_final_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                          int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
+                                                          double* __restrict__ wA, double* __restrict__ wB,
+                                                          double* __restrict__ sigma, double* __restrict__ info) {
+  rank1_final_body(x, y, n, k, x_is_A, ctl, wA, wB, sigma, info);
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -309,6 +375,8 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
     double* out = (s & 1) ? buf1 : buf0;
     hipLaunchKernelGGL(syrk_step_kernel, grid, block, panel_lds(n), st, in, n, n, n, out, ctl, s, s & 1);
   }
+  // (a single-workgroup fusion of the three finish kernels was measured: no faster than these three
+  // parallel launches, so the epilogue stays split)
   hipLaunchKernelGGL(rank1_seed_y_kernel, dim3((k + 31) / 32), dim3(256), (size_t)n * sizeof(double), st,
                      M0, n, k, buf0, buf1, ctl, n_squarings & 1, yv);
   hipLaunchKernelGGL(rank1_x_kernel, dim3((n + 3) / 4), dim3(256), 0, st, M0, n, k, yv, xv);
