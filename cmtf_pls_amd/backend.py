@@ -82,6 +82,19 @@ class HipBackend:
         _lib.check(self._fn("mode0_contract", X2)(_ptr(X2), I, P, _ptr(u), _ptr(Z), int(masked), _ptr(ws), ws.numel(), self._stream()), "mode0_contract")
         return Z
 
+    def mode0_contract_yq(self, X2: torch.Tensor, Y: torch.Tensor, q: torch.Tensor, masked: bool,
+                          out: torch.Tensor) -> Optional[torch.Tensor]:
+        """Z = X x_0 (Y q) with u = Y q (tpls.py:102) formed inside the kernel; None when the shape is outside
+        the fused form (caller: rowdot + mode0_contract)."""
+        I, P = X2.shape
+        ws = self._workspace("contract", self.lib.cmtfpls_mode0_contract_workspace_bytes(I, P))
+        rc = self._fn("mode0_contract_yq", X2)(_ptr(X2), I, P, _ptr(Y), Y.stride(0), Y.shape[1], _ptr(q), _ptr(out), int(masked),
+                                               _ptr(ws), ws.numel(), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "mode0_contract_yq")
+        return out
+
     def colscale(self, Z: torch.Tensor, colcnt: torch.Tensor, n_samples: float) -> None:
         _lib.check(self.lib.cmtfpls_colscale_f64(_ptr(Z), Z.numel(), _ptr(colcnt), float(n_samples), self._stream()), "colscale")
 
@@ -146,6 +159,25 @@ class HipBackend:
     def score(self, X2, A, B, wA, wB, rowcnt, out) -> torch.Tensor:
         _lib.check(self._fn("score", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), self._stream()), "score")
         return out
+
+    def score_gram(self, X2, A, B, wA, wB, rowcnt, out, Y: torch.Tensor, qpart: torch.Tensor) -> Optional[torch.Tensor]:
+        """score + the per-workgroup partial sums of Y^T t into qpart (n_partials x M); None when M > 64."""
+        assert qpart.numel() >= self.n_partials * Y.shape[1] and qpart.is_contiguous()
+        rc = self._fn("score_gram", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out),
+                                        _ptr(Y), Y.stride(0), Y.shape[1], _ptr(qpart), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "score_gram")
+        return out
+
+    def q_update(self, q: torch.Tensor, qpart: Optional[torch.Tensor] = None, normalize: bool = True,
+                 G: Optional[torch.Tensor] = None, q_prev: Optional[torch.Tensor] = None,
+                 du2: Optional[torch.Tensor] = None) -> None:
+        """The Y-side update in one launch: q = sum of qpart rows (optional), q /= |q| (optional),
+        du2 = (q - q_prev)^T G (q - q_prev) (optional).  tpls.py:100-103."""
+        M = q.numel()
+        _lib.check(self.lib.cmtfpls_q_update_f64(_ptr(qpart), self.n_partials if qpart is not None else 0, M, _ptr(q), int(normalize),
+                                                 _ptr(G), _ptr(q_prev), _ptr(du2), self._stream()), "q_update")
 
     # -- K6: tpls.py:109 ----------------------------------------------------------------------
     def deflate(self, X2, A, B, t, wA, wB) -> torch.Tensor:

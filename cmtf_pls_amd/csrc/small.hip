@@ -151,6 +151,74 @@ __global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ v,
   if (nrm && threadIdx.x == 0) nrm[0] = s;
 }
 
+// The Y-side update of one NIPALS iteration in one workgroup (tpls.py:100-103):
+//   q <- sum over workgroups of qpart (the score kernel's partial sums of Y^T t)      [qpart != null]
+//   q <- q / |q|                                                                      [normalize]
+//   du2 <- (q - q_prev)^T G (q - q_prev)  =  |Y q - Y q_prev|^2  with G = Y^T Y       [G != null]
+// Every sum has a fixed order (bit-reproducible).  M <= 64.
+__global__ __launch_bounds__(1024) void q_update_kernel(const double* __restrict__ qpart, int nblk, int M,
+                                                       double* __restrict__ q, int normalize,
+                                                       const double* __restrict__ G, const double* __restrict__ q_prev,
+                                                       double* __restrict__ du2) {
+  __shared__ double part[64][17];          // [group][m] for Mp = 16; reshaped below for wider M
+  __shared__ double qs[64];
+  __shared__ double dq[64];
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int Mp = (M <= 16) ? 16 : (M <= 32) ? 32 : 64;
+  const int ngrp = 1024 / Mp;               // 64, 32 or 16 groups of Mp lanes
+  const int m = tid & (Mp - 1), grp = tid / Mp;
+  double* pflat = &part[0][0];              // ngrp x (Mp + 1) <= 64 x 17 = 16 x 65 + ... fits 1088 doubles
+  if (qpart) {
+    // batches of 16 independent loads (clamped address, masked value): one memory latency per batch
+    double sacc = 0.0;
+    const int msafe = (m < M) ? m : 0;
+    for (int b0 = grp; b0 < nblk; b0 += 16 * ngrp) {
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int b = b0 + k * ngrp;
+        v[k] = qpart[(int64_t)((b < nblk) ? b : nblk - 1) * M + msafe];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sacc += (b0 + k * ngrp < nblk) ? v[k] : 0.0;
+    }
+    if (m >= M) sacc = 0.0;
+    pflat[grp * (Mp + 1) + m] = sacc;
+    __syncthreads();
+    if (tid < M) {
+      double tot = 0.0;
+      for (int g = 0; g < ngrp; ++g) tot += pflat[g * (Mp + 1) + tid];
+      qs[tid] = tot;
+    }
+  } else if (tid < M) {
+    qs[tid] = q[tid];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // wavefront 0: norm by a butterfly over the (zero padded) 64 lanes
+    double v = (lane < M) ? qs[lane] : 0.0;
+    if (normalize) {
+      const double nrm = sqrt(wave_sum(v * v));
+      v = v / nrm;
+    }
+    if (lane < M) {
+      q[lane] = v;
+      if (G) dq[lane] = v - q_prev[lane];
+    }
+  }
+  if (G) {
+    __syncthreads();
+    double sacc = 0.0;
+    for (int idx = tid; idx < M * M; idx += 1024) {
+      const int i = idx / M, j = idx - i * M;
+      sacc = fma(dq[i] * G[idx], dq[j], sacc);
+    }
+    sacc = block_sum(sacc, red);
+    if (tid == 0) du2[0] = sacc;
+  }
+}
+
 __global__ __launch_bounds__(256) void colscale_kernel(double* __restrict__ Z, int64_t P, const double* __restrict__ cnt, double n_samples) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c < P) Z[c] = (cnt[c] > 0.0) ? Z[c] / cnt[c] * n_samples : 0.0;
@@ -235,6 +303,14 @@ int cmtfpls_normalize_f64(double* v, int64_t n, double* nrm, void* stream) {
   if (!v || n <= 0) { set_error("normalize: bad argument"); return CMTFPLS_EINVAL; }
   hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, nrm);
   return check_launch("normalize");
+}
+
+int cmtfpls_q_update_f64(const double* qpart, int nblk, int M, double* q, int normalize, const double* G, const double* q_prev,
+                         double* du2, void* stream) {
+  if (!q || M <= 0 || (qpart && nblk <= 0) || (G && (!q_prev || !du2))) { set_error("q_update: bad argument"); return CMTFPLS_EINVAL; }
+  if (M > 64) { set_error("q_update: more than 64 responses; use gram_tn + normalize + rowdot"); return CMTFPLS_EUNSUPPORTED; }
+  hipLaunchKernelGGL(q_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, qpart, nblk, M, q, normalize, G, q_prev, du2);
+  return check_launch("q_update");
 }
 
 int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_samples, void* stream) {

@@ -40,17 +40,60 @@ static ContractPlan plan_contract(int64_t I, int64_t P, int elem) {
   return p;
 }
 
+// u[i] = sum_m Y[i, m] q[m] for the rows [r0, r1) of one workgroup, into LDS (YQ variants: the Y
+// update u = Y q of tpls.py:102 is formed where it is consumed instead of by a launch of its own).
+// L = 16 / 32 / 64 lanes share a row (coalesced read of the Y row), summed by a butterfly.
+template <int L>
+__device__ __forceinline__ void rows_times_q_impl(const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q,
+                                                  int64_t r0, int64_t r1, double* __restrict__ us) {
+  constexpr int ngrp = kSweepThreads / L;
+  const int sub = threadIdx.x & (L - 1), grp = threadIdx.x / L;
+  const double qm = (sub < M) ? q[sub] : 0.0;
+  const int msafe = (sub < M) ? sub : 0;
+  // every group runs the same number of trips (the shuffles need all lanes): rows past r1 are clamped
+  const int nrows = (int)(r1 - r0);
+  const int trips = (nrows + ngrp - 1) / ngrp;
+  const double* __restrict__ Yb = Y + r0 * ldy + msafe;
+  constexpr int K = 4;                                  // rows in flight per lane group
+  for (int tr = 0; tr < trips; tr += K) {
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int rr = (tr + k) * ngrp + grp;
+      v[k] = Yb[(int64_t)((rr < nrows) ? rr : nrows - 1) * ldy] * qm;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int rr = (tr + k) * ngrp + grp;
+#pragma unroll
+      for (int off = L >> 1; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+      if (sub == 0 && rr < nrows) us[rr] = v[k];
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void rows_times_q(const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q,
+                                             int64_t r0, int64_t r1, double* __restrict__ us) {
+  if (M <= 16) rows_times_q_impl<16>(Y, ldy, M, q, r0, r1, us);
+  else if (M <= 32) rows_times_q_impl<32>(Y, ldy, M, q, r0, r1, us);
+  else rows_times_q_impl<64>(Y, ldy, M, q, r0, r1, us);
+}
+
 // MODE 0: plain (NaN propagates, as np.einsum)  1: NaN -> 0  2: statistics (u == 1, NaN -> 0, count)
-template <typename T, int MODE>
+// YQ: u is not read; u[i] = Y[i, :] . q is formed per workgroup in LDS (dynamic, rows_per_block doubles)
+template <typename T, int MODE, bool YQ>
 __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
-    double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block) {
+    double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block,
+    const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q) {
+  extern __shared__ double us[];
   constexpr int V = VecOf<T>::N;
   constexpr int U = kContractU;
   using VT = typename VecOf<T>::type;
   const int64_t cbase = (int64_t)blockIdx.x * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  if (YQ) rows_times_q(Y, ldy, M, q, r0, r1, us);
   double acc[U][V];
   double cnt[U][V];
   bool ok[U];
@@ -67,7 +110,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     double uu[RU];
 #pragma unroll
     for (int s = 0; s < RU; ++s) {
-      uu[s] = (MODE == 2) ? 1.0 : u[r + s];
+      uu[s] = (MODE == 2) ? 1.0 : YQ ? us[r + s - r0] : u[r + s];
 #pragma unroll
       for (int g = 0; g < U; ++g)
         if (ok[g]) x[s][g] = ld_stream(reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V));
@@ -91,7 +134,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
         }
   }
   for (; r < r1; ++r) {
-    const double us = (MODE == 2) ? 1.0 : u[r];
+    const double ur = (MODE == 2) ? 1.0 : YQ ? us[r - r0] : u[r];
 #pragma unroll
     for (int g = 0; g < U; ++g)
       if (ok[g]) {
@@ -100,10 +143,10 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
         for (int e = 0; e < V; ++e) {
           const T xv = x.e[e];
           if (MODE == 0) {
-            acc[g][e] = fma((double)xv, us, acc[g][e]);
+            acc[g][e] = fma((double)xv, ur, acc[g][e]);
           } else {
             const bool obs = (xv == xv);
-            acc[g][e] = fma(obs ? (double)xv : 0.0, us, acc[g][e]);
+            acc[g][e] = fma(obs ? (double)xv : 0.0, ur, acc[g][e]);
             if (MODE == 2) cnt[g][e] += obs ? 1.0 : 0.0;
           }
         }
@@ -170,10 +213,13 @@ void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, h
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid), dim3(256), 0, st, part, nrows, P, out);
 }
 
+// Y != nullptr: the YQ form (u = Y q formed in the kernel; u itself is not read)
 template <typename T, int MODE>
 static int run_contract(const T* X, int64_t I, int64_t P, const double* u, double* out, double* cnt_out,
-                        void* ws, size_t ws_bytes, hipStream_t st) {
-  if (!X || !out || I <= 0 || P <= 0 || (MODE != 2 && !u) || (MODE == 2 && !cnt_out)) {
+                        void* ws, size_t ws_bytes, hipStream_t st,
+                        const double* Y = nullptr, int ldy = 0, int M = 0, const double* q = nullptr) {
+  const bool yq = Y != nullptr;
+  if (!X || !out || I <= 0 || P <= 0 || (MODE != 2 && !u && !yq) || (MODE == 2 && !cnt_out) || (yq && (!q || M <= 0 || ldy < M))) {
     set_error("mode0_contract/colstats: bad argument");
     return CMTFPLS_EINVAL;
   }
@@ -184,10 +230,21 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   double* part = static_cast<double*>(ws);
   double* cntpart = (MODE == 2) ? part + (size_t)p.row_blocks * P : nullptr;
   const dim3 grid(p.col_tiles, p.row_blocks);
-  if (p.vec)
-    hipLaunchKernelGGL((contract_vec_kernel<T, MODE>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart, p.rows_per_block);
-  else
+  if (yq) {
+    // supported: vector shape, M <= 64 (one Y row per wavefront pass), the workgroup's u chunk within 64 KB of LDS
+    const size_t lds = (size_t)p.rows_per_block * sizeof(double);
+    if (!p.vec || M > 64 || lds > 64 * 1024 || MODE == 2) {
+      set_error("mode0_contract_yq: shape outside the fused form; form u = Y q with rowdot and use mode0_contract");
+      return CMTFPLS_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
+                       p.rows_per_block, Y, ldy, M, q);
+  } else if (p.vec) {
+    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
+                       p.rows_per_block, nullptr, 0, 0, nullptr);
+  } else {
     hipLaunchKernelGGL((contract_scalar_kernel<T, MODE>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart, p.rows_per_block);
+  }
   launch_reduce_rows(part, p.row_blocks, P, out, st);
   if (MODE == 2) launch_reduce_rows(cntpart, p.row_blocks, P, cnt_out, st);
   return check_launch("mode0_contract");
@@ -217,11 +274,17 @@ __device__ __forceinline__ double dot_pack(const Pack<T, V>& x, const double* sB
 // ------------------------------------------------------------------------------------------
 // score: t[i] = sum_c X[i,c] wA[c/B] wB[c%B]      one wavefront per row
 // ------------------------------------------------------------------------------------------
-template <typename T, bool MASKED, bool VEC>
-__global__ __launch_bounds__(kSweepThreads) void score_kernel(
+// GRAM: also the partial sums of Y^T t (tpls.py:100) of this workgroup's rows: lane m < M of every
+// wavefront accumulates t[i] * Y[i, m] over its rows, the wavefronts are added in index order and the
+// workgroup writes qpart[blockIdx.x, 0:M]; a small kernel adds the workgroups in index order.
+template <typename T, bool MASKED, bool VEC, bool GRAM>
+__global__ __launch_bounds__(kSweepThreads) __attribute__((amdgpu_waves_per_eu(5))) void score_kernel(
     const T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ wA,
-    const double* __restrict__ wB, const double* __restrict__ rowcnt, double* __restrict__ t) {
+    const double* __restrict__ wB, const double* __restrict__ rowcnt, double* __restrict__ t,
+    const double* __restrict__ Y, int ldy, int M, double* __restrict__ qpart) {
   extern __shared__ double lds[];
+  __shared__ double qs[kSweepThreads / kWave][kWave];
+  double qacc = 0.0;
   double* sA = lds;
   double* sB = lds + ((A + 1) & ~1);
   stage_loadings(sA, sB, wA, wB, A, B);
@@ -235,6 +298,8 @@ __global__ __launch_bounds__(kSweepThreads) void score_kernel(
   const KronWalk w0(c0, step, B);
   for (int64_t row = (int64_t)blockIdx.x * (kSweepThreads / kWave) + (threadIdx.x >> 6); row < I; row += nwaves) {
     const T* __restrict__ xr = X + row * P;
+    double yv = 0.0;
+    if (GRAM) yv = Y[row * ldy + ((lane < M) ? lane : 0)];     // in flight while the row streams
     double acc = 0.0;
     KronWalk w = w0;
     int64_t c = c0;
@@ -254,8 +319,20 @@ __global__ __launch_bounds__(kSweepThreads) void score_kernel(
       acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x, sB + w.k), acc);
       w.next();
     }
-    acc = wave_sum(acc);
-    if (lane == 0) t[row] = MASKED ? acc / rowcnt[row] * (double)P : acc;
+    acc = wave_sum(acc);                                        // identical bits in every lane
+    const double ti = MASKED ? acc / rowcnt[row] * (double)P : acc;
+    if (lane == 0) t[row] = ti;
+    if (GRAM) qacc = fma(ti, yv, qacc);
+  }
+  if (GRAM) {
+    qs[threadIdx.x >> 6][lane] = qacc;
+    __syncthreads();
+    if (threadIdx.x < M) {
+      double tot = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < kSweepThreads / kWave; ++wv) tot += qs[wv][threadIdx.x];
+      qpart[(int64_t)blockIdx.x * M + threadIdx.x] = tot;
+    }
   }
 }
 
@@ -512,16 +589,22 @@ static bool vec_ok(const T* X, int B) {
 static bool shape_ok(int64_t I, int A, int B) { return I > 0 && A > 0 && B > 0; }
 static constexpr size_t kMaxLoadingsLds = 96 * 1024;
 
+// Y != nullptr: also writes the kSweepBlocks x M partial sums of Y^T t into qpart
 template <typename T>
 static int run_score(const T* X, int64_t I, int A, int B, const double* wA, const double* wB,
-                     const double* rowcnt, double* t, hipStream_t st) {
+                     const double* rowcnt, double* t, hipStream_t st,
+                     const double* Y = nullptr, int ldy = 0, int M = 0, double* qpart = nullptr) {
   if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("score: bad argument"); return CMTFPLS_EINVAL; }
+  const bool gram = Y != nullptr;
+  if (gram && (!qpart || M <= 0 || ldy < M)) { set_error("score_gram: bad argument"); return CMTFPLS_EINVAL; }
+  if (gram && M > kWave) { set_error("score_gram: more than 64 responses; use score + gram_tn"); return CMTFPLS_EUNSUPPORTED; }
   const size_t lds = loadings_lds_bytes(A, B);
   if (lds > kMaxLoadingsLds) { set_error("score: A + B loadings exceed LDS; choose a more balanced (A, B) split"); return CMTFPLS_EUNSUPPORTED; }
   const bool v = vec_ok(X, B), m = rowcnt != nullptr;
   const dim3 g(kSweepBlocks), b(kSweepThreads);
-#define LAUNCH(M, V) hipLaunchKernelGGL((score_kernel<T, M, V>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t)
-  if (m && v) LAUNCH(true, true); else if (m) LAUNCH(true, false); else if (v) LAUNCH(false, true); else LAUNCH(false, false);
+#define LAUNCH(MS, V, G) hipLaunchKernelGGL((score_kernel<T, MS, V, G>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart)
+  if (gram) { if (m && v) LAUNCH(true, true, true); else if (m) LAUNCH(true, false, true); else if (v) LAUNCH(false, true, true); else LAUNCH(false, false, true); }
+  else      { if (m && v) LAUNCH(true, true, false); else if (m) LAUNCH(true, false, false); else if (v) LAUNCH(false, true, false); else LAUNCH(false, false, false); }
 #undef LAUNCH
   return check_launch("score");
 }
@@ -615,6 +698,26 @@ int cmtfpls_mode0_contract_f32(const float* X, int64_t I, int64_t P, const doubl
 int cmtfpls_mode0_contract_f64(const double* X, int64_t I, int64_t P, const double* u, double* Z, int masked, void* ws, size_t n, void* s) {
   return masked ? run_contract<double, 1>(X, I, P, u, Z, nullptr, ws, n, (hipStream_t)s)
                 : run_contract<double, 0>(X, I, P, u, Z, nullptr, ws, n, (hipStream_t)s);
+}
+int cmtfpls_mode0_contract_yq_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, const double* q,
+                                  double* Z, int masked, void* ws, size_t n, void* s) {
+  return masked ? run_contract<float, 1>(X, I, P, nullptr, Z, nullptr, ws, n, (hipStream_t)s, Y, ldy, M, q)
+                : run_contract<float, 0>(X, I, P, nullptr, Z, nullptr, ws, n, (hipStream_t)s, Y, ldy, M, q);
+}
+int cmtfpls_mode0_contract_yq_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, const double* q,
+                                  double* Z, int masked, void* ws, size_t n, void* s) {
+  return masked ? run_contract<double, 1>(X, I, P, nullptr, Z, nullptr, ws, n, (hipStream_t)s, Y, ldy, M, q)
+                : run_contract<double, 0>(X, I, P, nullptr, Z, nullptr, ws, n, (hipStream_t)s, Y, ldy, M, q);
+}
+int cmtfpls_score_gram_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt,
+                           double* t, const double* Y, int ldy, int M, double* qpart, void* s) {
+  if (!Y) { set_error("score_gram: Y is null"); return CMTFPLS_EINVAL; }
+  return run_score<float>(X, I, A, B, wA, wB, rowcnt, t, (hipStream_t)s, Y, ldy, M, qpart);
+}
+int cmtfpls_score_gram_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt,
+                           double* t, const double* Y, int ldy, int M, double* qpart, void* s) {
+  if (!Y) { set_error("score_gram: Y is null"); return CMTFPLS_EINVAL; }
+  return run_score<double>(X, I, A, B, wA, wB, rowcnt, t, (hipStream_t)s, Y, ldy, M, qpart);
 }
 int cmtfpls_center_f32(float* X, int64_t I, int64_t P, const double* mean, double* rowcnt, double* ssq_part, void* s) {
   return run_center<float>(X, I, P, mean, rowcnt, ssq_part, (hipStream_t)s);

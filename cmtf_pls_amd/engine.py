@@ -318,7 +318,17 @@ class FitRun:
         self.use_graphs = False
         self._graphs = {}
         self._graph_error = None
-        if algorithm == "direct" and comm.world > 1:
+        # Fused Y side (one block, M <= 64): u = Y q is formed inside the contraction and Y^T t inside the
+        # score kernel, so an iteration has no launch of its own for either; q lives in two buffers that
+        # alternate by parity (a captured graph holds their addresses) and |du|^2 is the quadratic form
+        # dq^T (Y^T Y) dq.  Other shapes keep the separate gram_tn / normalize / rowdot launches.
+        self._fused = (algorithm == "direct" and len(self.blocks) == 1 and not coupled and M <= 64
+                       and all(hasattr(be, f) for f in ("mode0_contract_yq", "score_gram", "q_update")))
+        if self._fused:
+            self.Gy = be.empty(M, M)
+            self.qbuf = [be.zeros(M), be.zeros(M)]
+            self.qpart = be.empty(int(be.n_partials) * M)
+        elif algorithm == "direct" and comm.world > 1:
             self.Gy = be.empty(M, M)
             self.q_prev = be.zeros(M)
         if algorithm == "xcov":
@@ -339,7 +349,10 @@ class FitRun:
         if self.algorithm == "direct":
             self.u.copy_(self.Y[:, 0])                            # tpls.py:78
             self._parity = 0
-            if comm.world > 1:
+            if self._fused:
+                self.qbuf[0].zero_()
+                self.qbuf[0][0] = 1.0                             # u_0 = Y[:, 0] = Y e_0 exactly
+            if self._fused or comm.world > 1:
                 be.gram_tn(self.Y, self.Y, out=self.Gy)
                 comm.allreduce(self.Gy)
             return
@@ -443,6 +456,8 @@ class FitRun:
         if self.algorithm == "xcov":
             return self._iterate_xcov(it)
         be, comm = self.eng.be, self.eng.comm
+        if self._fused:
+            return self._iterate_fused(it)
         self._executed += 1
         sharded = comm.world > 1
         par = self._parity                       # which of the two u buffers holds the current u
@@ -506,6 +521,67 @@ class FitRun:
         self._parity ^= 1                        # the previous ITERATION's q, not the rejected attempt's)
         return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))          # tpls.py:103
 
+    def _iterate_fused(self, it: int) -> Optional[float]:
+        """The direct iteration for one X block with the Y side fused into the two sweeps:
+        contraction with u = Y q formed in the kernel (tpls.py:80-83 + 102), rank-1 (84-90), score with the
+        partial sums of Y^T t (92-100), and ONE small launch for q = sum / norm and |du|^2 (100-103)."""
+        be, comm = self.eng.be, self.eng.comm
+        self._executed += 1
+        sharded = comm.world > 1
+        par = self._parity
+        q_cur, q_new = self.qbuf[par], self.qbuf[par ^ 1]
+        blk, X2 = self.blocks[0], self.X2[0]
+        rc = blk.rowcnt if blk.has_miss else None
+
+        def seg_contract():
+            if be.mode0_contract_yq(X2, self.Y, q_cur, blk.has_miss, out=self.Zs[0]) is None:
+                be.rowdot(self.Y, q_cur, self.u, None)                           # shape outside the fused form
+                be.mode0_contract(X2, self.u, blk.has_miss, out=self.Zs[0])
+
+        def seg_colscale():
+            if blk.has_miss:
+                be.colscale(self.Zs[0], blk.colcnt, self.n_total)                # missingvals.py:17-19
+
+        def seg_loadings_scores():
+            self.eng._rank1(blk, self.Zs[0], self.wA[0], self.wB[0], info=self.status[1:3],
+                            n_squarings=self.sq_budget[0], fac=self.fac[0], tol=self.tol)
+            be.score_gram(X2, blk.A, blk.B, self.wA[0], self.wB[0], rc, self.Ts[0], self.Y, self.qpart)
+            if sharded:
+                be.q_update(q_new, self.qpart, normalize=False)                  # local Y^T t; all-reduced next
+
+        def seg_y_update():
+            if sharded:
+                be.q_update(q_new, None, normalize=True, G=self.Gy, q_prev=q_cur, du2=self.status[0:1])
+            else:
+                be.q_update(q_new, self.qpart, normalize=True, G=self.Gy, q_prev=q_cur, du2=self.status[0:1])
+
+        first = True
+        while True:
+            budgets = tuple(self.sq_budget)
+            if not sharded:
+                def whole():
+                    if first:
+                        seg_contract()
+                        seg_colscale()
+                    seg_loadings_scores()
+                    seg_y_update()
+                self._run(("fiter", par, budgets, first), whole)
+            else:
+                if first:
+                    self._run(("fcontract", par), seg_contract)
+                    comm.allreduce(self.Zs[0])
+                    seg_colscale()
+                self._run(("floadings", par, budgets), seg_loadings_scores)
+                comm.allreduce(q_new)
+                self._run(("fyupdate", par), seg_y_update)
+            host = self._read_status()
+            if not self._update_budgets(host):
+                break
+            first = False
+        self._parity ^= 1
+        self.q = q_new
+        return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))          # tpls.py:103
+
     def finish_component(self, a: int) -> None:
         be, comm = self.eng.be, self.eng.comm
         self.n_iter.append(self._executed)
@@ -529,7 +605,9 @@ class FitRun:
                 for b, blk in enumerate(self.blocks):
                     ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))
             be.rowdot(self.Y, self.q, self.u, None)                              # u = Y q (tpls.py:102)
-        if self.algorithm == "direct" and self._parity == 1:
+        if self.algorithm == "direct" and self._fused:
+            be.rowdot(self.Y, self.q, self.u, None)      # u = Y q of the last iteration (tpls.py:102), once
+        elif self.algorithm == "direct" and self._parity == 1:
             self.u.copy_(self.u_new)                     # make self.u the current u again; the two buffers keep
             self._parity = 0                             # their identity (captured graphs hold their addresses)
         self.T[:, a].copy_(self.t)

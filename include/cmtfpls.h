@@ -65,6 +65,14 @@ int cmtfpls_mode0_contract_f32(const float* X, int64_t I, int64_t P, const doubl
                                int masked, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_mode0_contract_f64(const double* X, int64_t I, int64_t P, const double* u, double* Z,
                                int masked, void* ws, size_t ws_bytes, void* stream);
+/* The same contraction with u = Y q (tpls.py:102, `Y @ Y_load`) formed inside the kernel instead of
+ * being read: Z[c] = sum_i X[i,c] * (Y[i,:] . q).  Saves the u = Y q launch of every iteration.
+ * Vector shapes (P % (16/sizeof(T)) == 0) with M <= 64 only: CMTFPLS_EUNSUPPORTED otherwise (form u with
+ * cmtfpls_rowdot_f64 and call cmtfpls_mode0_contract_*).  Same workspace as mode0_contract. */
+int cmtfpls_mode0_contract_yq_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M,
+                                  const double* q, double* Z, int masked, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_mode0_contract_yq_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M,
+                                  const double* q, double* Z, int masked, void* ws, size_t ws_bytes, void* stream);
 /* Z[c] = colcnt[c] > 0 ? Z[c] / colcnt[c] * n_samples : 0     (missingvals.py:17-19) */
 int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_samples, void* stream);
 
@@ -134,6 +142,23 @@ int cmtfpls_score_f32(const float* X, int64_t I, int A, int B, const double* wA,
                       const double* rowcnt, double* t, void* stream);
 int cmtfpls_score_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB,
                       const double* rowcnt, double* t, void* stream);
+
+/* score + the partial sums of Y^T t (tpls.py:100, `Y.T @ X_scores`) of every workgroup's rows:
+ * qpart is (cmtfpls_sweep_partials() x M) row-major; cmtfpls_q_update_f64 adds the rows in index order.
+ * M <= 64 (CMTFPLS_EUNSUPPORTED otherwise: use score + gram_tn). */
+int cmtfpls_score_gram_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                           const double* rowcnt, double* t, const double* Y, int ldy, int M, double* qpart,
+                           void* stream);
+int cmtfpls_score_gram_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                           const double* rowcnt, double* t, const double* Y, int ldy, int M, double* qpart,
+                           void* stream);
+/* The Y-side update of one iteration in one launch (tpls.py:100-103), every step optional:
+ *   qpart != NULL : q[m] = sum_b qpart[b*M + m]  (b < nblk, fixed order)
+ *   normalize != 0: q /= ||q||_2                                            (tpls.py:101)
+ *   G != NULL     : du2[0] = (q - q_prev)^T G (q - q_prev) = |Y q - Y q_prev|^2 for G = Y^T Y (tpls.py:103)
+ * A sharded fit calls it twice around the all-reduce of q (first the sum, then the rest).  M <= 64. */
+int cmtfpls_q_update_f64(const double* qpart, int nblk, int M, double* q, int normalize, const double* G,
+                         const double* q_prev, double* du2, void* stream);
 
 /* ---- K6 rank-1 deflation: X -= outer([t, w_J, w_K])  tpls.py:109; cmtf.py:130-131 ------------
  * X[i,c] -= t[i] * wA[c / B] * wB[c % B] in place, one read + one write of X.

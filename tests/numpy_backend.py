@@ -44,6 +44,34 @@ class NumpyBackend:
             return out
         return z
 
+    n_partials = 4          # partial rows of score_gram (the HIP backend has one per workgroup)
+
+    def mode0_contract_yq(self, X2, Y, q, masked, out):
+        if X2.shape[1] % 2 == 1:
+            return None        # stands for "shape outside the fused form": the engine must fall back
+        return self.mode0_contract(X2, Y @ q, masked, out=out)
+
+    def score_gram(self, X2, A, B, wA, wB, rowcnt, out, Y, qpart):
+        if Y.shape[1] > 64:
+            return None
+        self.score(X2, A, B, wA, wB, rowcnt, out)
+        M = Y.shape[1]
+        parts = qpart[: self.n_partials * M].view(self.n_partials, M)
+        parts.zero_()
+        for g in range(self.n_partials):                      # rows dealt to the partials round-robin
+            parts[g] = Y[g::self.n_partials].t() @ out[g::self.n_partials]
+        return out
+
+    def q_update(self, q, qpart=None, normalize=True, G=None, q_prev=None, du2=None):
+        M = q.numel()
+        if qpart is not None:
+            q.copy_(qpart[: self.n_partials * M].view(self.n_partials, M).sum(0))
+        if normalize:
+            q /= torch.linalg.norm(q)
+        if G is not None:
+            d = q - q_prev
+            du2[0] = float(d @ G @ d)
+
     def xcov(self, X2, Y, masked, out=None, mixed=False):
         x = _np(X2).astype(np.float64)
         if masked:

@@ -435,3 +435,82 @@ def test_sweeps_do_not_depend_on_address_bits(be, shape, where):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     np.testing.assert_allclose(host(outs[0][1]), O.score_contract(x.reshape(I, A, B), [host(wa), host(wb)]), **RT)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape,M", [((37, 10, 8), 4), ((300, 16, 16), 16), ((1000, 16, 16), 17), ((50, 128, 128), 33),
+                                     ((129, 4, 64), 64), ((5000, 2, 4), 1)])
+def test_mode0_contract_yq(be, shape, M, dt, masked):
+    """Contraction with u = Y q formed inside the kernel (tpls.py:80-83 with tpls.py:102 folded in)."""
+    I, A, B = shape
+    x = make_x(shape, dt, nan_frac=0.2 if masked else 0.0, seed=91)
+    rng = np.random.default_rng(92)
+    y, q = rng.normal(size=(I, M)), rng.normal(size=M)
+    Z = be.mode0_contract_yq(dev(x, TDT[dt]), dev(y), dev(q), masked, out=be.empty(A * B))
+    assert Z is not None
+    u = y @ q
+    x0 = np.nan_to_num(x) if masked else x
+    want = x0.T @ u
+    scale = np.abs(x0).T @ np.abs(u) + 1e-300
+    assert np.max(np.abs(host(Z) - want) / scale) < 1e-13
+    # strided Y (a column block of a wider matrix), as the engine may pass it
+    ywide = dev(np.concatenate([y, rng.normal(size=(I, 3))], axis=1))
+    Z2 = be.mode0_contract_yq(dev(x, TDT[dt]), ywide[:, :M], dev(q), masked, out=be.empty(A * B))
+    assert torch.equal(Z2, Z)
+
+
+def test_mode0_contract_yq_unsupported_shapes(be):
+    rng = np.random.default_rng(93)
+    x = dev(rng.normal(size=(40, 7 * 9)), torch.float32)              # P % 4 != 0: scalar shape
+    assert be.mode0_contract_yq(x, dev(rng.normal(size=(40, 3))), dev(rng.normal(size=3)), False, out=be.empty(63)) is None
+    x = dev(rng.normal(size=(40, 64)), torch.float32)                 # more than 64 responses
+    assert be.mode0_contract_yq(x, dev(rng.normal(size=(40, 65))), dev(rng.normal(size=65)), False, out=be.empty(64)) is None
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape,M", [((37, 10, 8), 4), ((100, 38, 65), 3), ((300, 16, 16), 16), ((3000, 16, 16), 17),
+                                     ((50, 128, 128), 64), ((64, 1, 20), 1)])
+def test_score_gram_and_q_update(be, shape, M, dt, masked):
+    """score + partial sums of Y^T t (tpls.py:92-100), then the one-launch Y-side update (tpls.py:100-103)."""
+    I, A, B = shape
+    x = make_x(shape, dt, nan_frac=0.2 if masked else 0.0, seed=94)
+    rng = np.random.default_rng(95)
+    wa, wb = rng.normal(size=A), rng.normal(size=B)
+    y = rng.normal(size=(I, M))
+    X, Y = dev(x, TDT[dt]), dev(y)
+    rowcnt = dev((~np.isnan(x)).sum(1).astype(float)) if masked else None
+    t_ref = be.score(X, A, B, dev(wa), dev(wb), rowcnt, be.empty(I))
+    t = be.empty(I)
+    qpart = be.empty(be.n_partials * M)
+    assert be.score_gram(X, A, B, dev(wa), dev(wb), rowcnt, t, Y, qpart) is not None
+    assert torch.equal(t, t_ref)                                        # the score itself is unchanged
+    th = host(t)
+    want_q = y.T @ th
+    scale = np.abs(y).T @ np.abs(th) + 1e-300
+    got_raw = host(qpart).reshape(be.n_partials, M).sum(0)
+    assert np.max(np.abs(got_raw - want_q) / scale) < 1e-13
+    # q_update: sum + normalise + quadratic form, all at once and in the two halves a sharded fit uses
+    G = y.T @ y
+    q_prev = rng.normal(size=M)
+    q_prev /= np.linalg.norm(q_prev)
+    q1, du1 = be.empty(M), be.empty(1)
+    be.q_update(q1, qpart, normalize=True, G=dev(G), q_prev=dev(q_prev), du2=du1)
+    qn = want_q / np.linalg.norm(want_q)
+    np.testing.assert_allclose(host(q1), qn, rtol=1e-11, atol=1e-13)
+    d = host(q1) - q_prev
+    np.testing.assert_allclose(host(du1)[0], d @ G @ d, rtol=1e-11)
+    np.testing.assert_allclose(host(du1)[0], np.sum((y @ host(q1) - y @ q_prev) ** 2), rtol=1e-9)   # = |du|^2 (tpls.py:103)
+    q2, du2 = be.empty(M), be.empty(1)
+    be.q_update(q2, qpart, normalize=False)
+    np.testing.assert_allclose(host(q2), want_q, rtol=0, atol=1e-13 * np.max(scale))
+    be.q_update(q2, None, normalize=True, G=dev(G), q_prev=dev(q_prev), du2=du2)
+    assert torch.equal(q2, q1) and torch.equal(du2, du1)
+
+
+def test_score_gram_more_than_64_responses_is_unsupported(be):
+    rng = np.random.default_rng(96)
+    X = dev(rng.normal(size=(20, 32)), torch.float32)
+    Y = dev(rng.normal(size=(20, 65)))
+    assert be.score_gram(X, 4, 8, dev(rng.normal(size=4)), dev(rng.normal(size=8)), None, be.empty(20), Y, be.empty(be.n_partials * 65)) is None
