@@ -172,11 +172,13 @@ class HipBackend:
 
     def q_update(self, q: torch.Tensor, qpart: Optional[torch.Tensor] = None, normalize: bool = True,
                  G: Optional[torch.Tensor] = None, q_prev: Optional[torch.Tensor] = None,
-                 du2: Optional[torch.Tensor] = None) -> None:
+                 du2: Optional[torch.Tensor] = None, nparts: Optional[int] = None) -> None:
         """The Y-side update in one launch: q = sum of qpart rows (optional), q /= |q| (optional),
         du2 = (q - q_prev)^T G (q - q_prev) (optional).  tpls.py:100-103."""
         M = q.numel()
-        _lib.check(self.lib.cmtfpls_q_update_f64(_ptr(qpart), self.n_partials if qpart is not None else 0, M, _ptr(q), int(normalize),
+        nrows = (nparts or self.n_partials) if qpart is not None else 0
+        assert qpart is None or (qpart.is_contiguous() and qpart.numel() >= nrows * M)
+        _lib.check(self.lib.cmtfpls_q_update_f64(_ptr(qpart), nrows, M, _ptr(q), int(normalize),
                                                  _ptr(G), _ptr(q_prev), _ptr(du2), self._stream()), "q_update")
 
     # -- K6: tpls.py:109 ----------------------------------------------------------------------

@@ -322,12 +322,14 @@ class FitRun:
         # score kernel, so an iteration has no launch of its own for either; q lives in two buffers that
         # alternate by parity (a captured graph holds their addresses) and |du|^2 is the quadratic form
         # dq^T (Y^T Y) dq.  Other shapes keep the separate gram_tn / normalize / rowdot launches.
-        self._fused = (algorithm == "direct" and len(self.blocks) == 1 and not coupled and M <= 64
+        # Coupled blocks: normalize(Y^T mean_b t_b) = normalize(sum_b Y^T t_b), so every block's score kernel
+        # adds its partial rows and the averaged score itself is only formed once per component.
+        self._fused = (algorithm == "direct" and M <= 64
                        and all(hasattr(be, f) for f in ("mode0_contract_yq", "score_gram", "q_update")))
         if self._fused:
             self.Gy = be.empty(M, M)
             self.qbuf = [be.zeros(M), be.zeros(M)]
-            self.qpart = be.empty(int(be.n_partials) * M)
+            self.qpart = be.empty(len(self.blocks), int(be.n_partials) * M)
         elif algorithm == "direct" and comm.world > 1:
             self.Gy = be.empty(M, M)
             self.q_prev = be.zeros(M)
@@ -530,30 +532,33 @@ class FitRun:
         sharded = comm.world > 1
         par = self._parity
         q_cur, q_new = self.qbuf[par], self.qbuf[par ^ 1]
-        blk, X2 = self.blocks[0], self.X2[0]
-        rc = blk.rowcnt if blk.has_miss else None
+        nparts = len(self.blocks) * int(be.n_partials)
 
         def seg_contract():
-            if be.mode0_contract_yq(X2, self.Y, q_cur, blk.has_miss, out=self.Zs[0]) is None:
-                be.rowdot(self.Y, q_cur, self.u, None)                           # shape outside the fused form
-                be.mode0_contract(X2, self.u, blk.has_miss, out=self.Zs[0])
+            for b, blk in enumerate(self.blocks):
+                if be.mode0_contract_yq(self.X2[b], self.Y, q_cur, blk.has_miss, out=self.Zs[b]) is None:
+                    be.rowdot(self.Y, q_cur, self.u, None)                       # shape outside the fused form
+                    be.mode0_contract(self.X2[b], self.u, blk.has_miss, out=self.Zs[b])
 
         def seg_colscale():
-            if blk.has_miss:
-                be.colscale(self.Zs[0], blk.colcnt, self.n_total)                # missingvals.py:17-19
+            for b, blk in enumerate(self.blocks):
+                if blk.has_miss:
+                    be.colscale(self.Zs[b], blk.colcnt, self.n_total)            # missingvals.py:17-19
 
         def seg_loadings_scores():
-            self.eng._rank1(blk, self.Zs[0], self.wA[0], self.wB[0], info=self.status[1:3],
-                            n_squarings=self.sq_budget[0], fac=self.fac[0], tol=self.tol)
-            be.score_gram(X2, blk.A, blk.B, self.wA[0], self.wB[0], rc, self.Ts[0], self.Y, self.qpart)
+            for b, blk in enumerate(self.blocks):
+                self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b], info=self.status[1 + 2 * b: 3 + 2 * b],
+                                n_squarings=self.sq_budget[b], fac=self.fac[b], tol=self.tol)
+                be.score_gram(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], blk.rowcnt if blk.has_miss else None,
+                              self.Ts[b], self.Y, self.qpart[b])
             if sharded:
-                be.q_update(q_new, self.qpart, normalize=False)                  # local Y^T t; all-reduced next
+                be.q_update(q_new, self.qpart, normalize=False, nparts=nparts)   # local sum_b Y^T t_b; all-reduced next
 
         def seg_y_update():
             if sharded:
                 be.q_update(q_new, None, normalize=True, G=self.Gy, q_prev=q_cur, du2=self.status[0:1])
             else:
-                be.q_update(q_new, self.qpart, normalize=True, G=self.Gy, q_prev=q_cur, du2=self.status[0:1])
+                be.q_update(q_new, self.qpart, normalize=True, G=self.Gy, q_prev=q_cur, du2=self.status[0:1], nparts=nparts)
 
         first = True
         while True:
@@ -569,7 +574,8 @@ class FitRun:
             else:
                 if first:
                     self._run(("fcontract", par), seg_contract)
-                    comm.allreduce(self.Zs[0])
+                    for b in range(len(self.blocks)):
+                        comm.allreduce(self.Zs[b])
                     seg_colscale()
                 self._run(("floadings", par, budgets), seg_loadings_scores)
                 comm.allreduce(q_new)
@@ -607,6 +613,8 @@ class FitRun:
             be.rowdot(self.Y, self.q, self.u, None)                              # u = Y q (tpls.py:102)
         if self.algorithm == "direct" and self._fused:
             be.rowdot(self.Y, self.q, self.u, None)      # u = Y q of the last iteration (tpls.py:102), once
+            if self.t.data_ptr() != self.Ts.data_ptr():
+                be.scores_mean(self.Ts, self.t)          # cmtf.py:120, once per component (the loop needs only Y^T t)
         elif self.algorithm == "direct" and self._parity == 1:
             self.u.copy_(self.u_new)                     # make self.u the current u again; the two buffers keep
             self._parity = 0                             # their identity (captured graphs hold their addresses)

@@ -56,16 +56,17 @@ class NumpyBackend:
             return None
         self.score(X2, A, B, wA, wB, rowcnt, out)
         M = Y.shape[1]
-        parts = qpart[: self.n_partials * M].view(self.n_partials, M)
+        parts = qpart.reshape(-1)[: self.n_partials * M].view(self.n_partials, M)
         parts.zero_()
         for g in range(self.n_partials):                      # rows dealt to the partials round-robin
             parts[g] = Y[g::self.n_partials].t() @ out[g::self.n_partials]
         return out
 
-    def q_update(self, q, qpart=None, normalize=True, G=None, q_prev=None, du2=None):
+    def q_update(self, q, qpart=None, normalize=True, G=None, q_prev=None, du2=None, nparts=None):
         M = q.numel()
         if qpart is not None:
-            q.copy_(qpart[: self.n_partials * M].view(self.n_partials, M).sum(0))
+            n = nparts or self.n_partials
+            q.copy_(qpart.reshape(-1)[: n * M].view(n, M).sum(0))
         if normalize:
             q /= torch.linalg.norm(q)
         if G is not None:
