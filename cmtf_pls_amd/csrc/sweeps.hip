@@ -164,6 +164,88 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     }
 }
 
+// Narrow blocks (P <= 128 vectors of 16 B, e.g. the I x 512 matrix block of a coupled fit): one row
+// needs only ncv = P / V threads, so the workgroup's 256 threads take RS = 256 / ncv rows at a time
+// (thread = (row lane, column vector)) and the RS row lanes are added in index order through LDS.
+// Same partial layout and same second kernel as contract_vec_kernel.
+template <typename T, int MODE, bool YQ>
+__global__ __launch_bounds__(kSweepThreads) void contract_narrow_kernel(
+    const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
+    double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block,
+    const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q, int ncv, int RS) {
+  extern __shared__ double us[];                       // YQ: rows_per_block doubles
+  constexpr int V = VecOf<T>::N;
+  using VT = typename VecOf<T>::type;
+  __shared__ double red[kSweepThreads * V];             // [row lane][column] = RS x P <= 256 V doubles
+  __shared__ double redc[(MODE == 2) ? kSweepThreads * V : 1];
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  if (YQ) rows_times_q(Y, ldy, M, q, r0, r1, us);
+  const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv;
+  const bool active = rl < RS;
+  const int64_t c = (int64_t)cv * V;
+  double acc[V], cnt[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { acc[e] = 0.0; cnt[e] = 0.0; }
+  if (active) {
+    constexpr int RU = kUnroll;
+    int64_t r = r0 + rl;
+    for (; r + (int64_t)(RU - 1) * RS < r1; r += (int64_t)RU * RS) {
+      VT x[RU];
+      double uu[RU];
+#pragma unroll
+      for (int s = 0; s < RU; ++s) {
+        const int64_t rr = r + (int64_t)s * RS;
+        uu[s] = (MODE == 2) ? 1.0 : YQ ? us[rr - r0] : u[rr];
+        x[s] = ld_stream(reinterpret_cast<const VT*>(X + rr * P + c));
+      }
+#pragma unroll
+      for (int s = 0; s < RU; ++s)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const T xv = x[s].e[e];
+          if (MODE == 0) {
+            acc[e] = fma((double)xv, uu[s], acc[e]);
+          } else {
+            const bool obs = (xv == xv);
+            acc[e] = fma(obs ? (double)xv : 0.0, uu[s], acc[e]);
+            if (MODE == 2) cnt[e] += obs ? 1.0 : 0.0;
+          }
+        }
+    }
+    for (; r < r1; r += RS) {
+      const double ur = (MODE == 2) ? 1.0 : YQ ? us[r - r0] : u[r];
+      const VT x = ld_stream(reinterpret_cast<const VT*>(X + r * P + c));
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const T xv = x.e[e];
+        if (MODE == 0) {
+          acc[e] = fma((double)xv, ur, acc[e]);
+        } else {
+          const bool obs = (xv == xv);
+          acc[e] = fma(obs ? (double)xv : 0.0, ur, acc[e]);
+          if (MODE == 2) cnt[e] += obs ? 1.0 : 0.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      red[(int64_t)rl * P + c + e] = acc[e];
+      if (MODE == 2) redc[(int64_t)rl * P + c + e] = cnt[e];
+    }
+  }
+  __syncthreads();
+  for (int64_t cc = threadIdx.x; cc < P; cc += kSweepThreads) {
+    double tot = 0.0, totc = 0.0;
+    for (int g = 0; g < RS; ++g) {
+      tot += red[(int64_t)g * P + cc];
+      if (MODE == 2) totc += redc[(int64_t)g * P + cc];
+    }
+    part[(int64_t)blockIdx.y * P + cc] = tot;
+    if (MODE == 2) cntpart[(int64_t)blockIdx.y * P + cc] = totc;
+  }
+}
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(kSweepThreads) void contract_scalar_kernel(
     const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
@@ -196,8 +278,20 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restri
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int64_t c = (int64_t)blockIdx.x * 32 + cx;
   double s = 0.0;
-  if (c < P)
-    for (int r = ry; r < nrows; r += 8) s += part[(int64_t)r * P + c];
+  if (c < P) {
+    // batches of 8 independent loads (clamped row, masked value), added in the same ascending order
+    const double* __restrict__ pc = part + c;
+    for (int r = ry; r < nrows; r += 64) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rr = r + 8 * k;
+        v[k] = pc[(int64_t)((rr < nrows) ? rr : nrows - 1) * P];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += (r + 8 * k < nrows) ? v[k] : 0.0;
+    }
+  }
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && c < P) {
@@ -230,15 +324,26 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   double* part = static_cast<double*>(ws);
   double* cntpart = (MODE == 2) ? part + (size_t)p.row_blocks * P : nullptr;
   const dim3 grid(p.col_tiles, p.row_blocks);
+  constexpr int Vt = 16 / (int)sizeof(T);
+  const int ncv = p.vec ? (int)(P / Vt) : 0;
+  const bool narrow = p.vec && ncv <= kSweepThreads / 2;          // at least two rows per workgroup pass
+  const int RS = narrow ? kSweepThreads / ncv : 1;
   if (yq) {
     // supported: vector shape, M <= 64 (one Y row per wavefront pass), the workgroup's u chunk within 64 KB of LDS
     const size_t lds = (size_t)p.rows_per_block * sizeof(double);
-    if (!p.vec || M > 64 || lds > 64 * 1024 || MODE == 2) {
+    if (!p.vec || M > 64 || lds > 48 * 1024 || MODE == 2) {
       set_error("mode0_contract_yq: shape outside the fused form; form u = Y q with rowdot and use mode0_contract");
       return CMTFPLS_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
-                       p.rows_per_block, Y, ldy, M, q);
+    if (narrow)
+      hipLaunchKernelGGL((contract_narrow_kernel<T, MODE, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
+                         p.rows_per_block, Y, ldy, M, q, ncv, RS);
+    else
+      hipLaunchKernelGGL((contract_vec_kernel<T, MODE, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
+                         p.rows_per_block, Y, ldy, M, q);
+  } else if (narrow) {
+    hipLaunchKernelGGL((contract_narrow_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
+                       p.rows_per_block, nullptr, 0, 0, nullptr, ncv, RS);
   } else if (p.vec) {
     hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
                        p.rows_per_block, nullptr, 0, 0, nullptr);
