@@ -15,7 +15,13 @@ constexpr int kWave = 64;
 #define CMTFPLS_SWEEP_BLOCKS 2048
 #endif
 #ifndef CMTFPLS_UNROLL
-#define CMTFPLS_UNROLL 4
+#define CMTFPLS_UNROLL 4          // rows in flight per thread in the contraction
+#endif
+#ifndef CMTFPLS_ROW_UNROLL
+#define CMTFPLS_ROW_UNROLL 8      // 16-byte loads in flight per lane in the wavefront-per-row sweeps (score, deflate)
+#endif
+#ifndef CMTFPLS_CONTRACT_BLOCKS
+#define CMTFPLS_CONTRACT_BLOCKS 1024   // workgroups of the contraction (its partial rows = this / column tiles)
 #endif
 #ifndef CMTFPLS_NT_LOAD
 #define CMTFPLS_NT_LOAD 1
@@ -26,6 +32,8 @@ constexpr int kWave = 64;
 constexpr int kSweepBlocks = CMTFPLS_SWEEP_BLOCKS;
 constexpr int kSweepThreads = 256;
 constexpr int kUnroll = CMTFPLS_UNROLL;
+constexpr int kRowUnroll = CMTFPLS_ROW_UNROLL;
+constexpr int kContractBlocks = CMTFPLS_CONTRACT_BLOCKS;   // measured: profiles/r01m_tune_sweeps.txt
 
 // 16-byte vector of T: float4 / double2 loads and stores (global_load_dwordx4).
 template <typename T, int N>

@@ -30,7 +30,7 @@ static ContractPlan plan_contract(int64_t I, int64_t P, int elem) {
   p.vec = (P % V == 0) ? 1 : 0;
   const int64_t tile = p.vec ? (int64_t)kSweepThreads * V * kContractU : kSweepThreads;
   p.col_tiles = (int)((P + tile - 1) / tile);
-  int64_t want = (kSweepBlocks + p.col_tiles - 1) / p.col_tiles;   // ~2048 workgroups in all
+  int64_t want = (kContractBlocks + p.col_tiles - 1) / p.col_tiles;   // ~1024 workgroups in all
   if (want < 1) want = 1;
   int64_t rpb = (I + want - 1) / want;
   if (rpb < 16) rpb = 16;                                           // amortise the partial store
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kSweepThreads) __attribute__((amdgpu_waves_per_eu(5
     double acc = 0.0;
     KronWalk w = w0;
     int64_t c = c0;
-    constexpr int UN = kUnroll;
+    constexpr int UN = kRowUnroll;
     for (; c + (UN - 1) * step < P; c += UN * step) {
       VT x[UN];
 #pragma unroll
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
     const double ti = t[row];
     KronWalk w = w0;
     int64_t c = c0;
-    constexpr int UN = kUnroll;
+    constexpr int UN = kRowUnroll;
     for (; c + (UN - 1) * step < P; c += UN * step) {
       VT x[UN];
 #pragma unroll

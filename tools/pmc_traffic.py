@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the X sweeps from the PMC counters -> profiles/pmc_traffic.json.
+
+Two separate rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE; each with --kernel-trace only, as the
+MI355X guide prescribes) over `bench.py --steps 5 --warmup 2 --no-cpu --graphs 0`; the counter unit is
+KB (x1024); FETCH_SIZE is doubled (gfx950 reports half of the bytes of a wide coalesced streaming read,
+MI355X_MICROARCH.md); WRITE_SIZE is taken as is; per launch = mean over the kernel's dispatches.
+Run on the GPU box:  python3 tools/pmc_traffic.py [out.json]
+(this process never touches the GPU; rocprofv3 is started with python3 directly after `--`)."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = {"contract_vec_kernel": 1, "score_kernel": 1, "deflate_kernel": 2, "center_kernel": 2,
+           "score_deflate_kernel": 2, "xcov_kernel": 1}
+XBYTES = 65536 * 128 * 128 * 4
+
+
+def one_pass(counter, outdir):
+    os.makedirs(outdir, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "p", "--",
+           "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--graphs", "0"]
+    with open(os.path.join(outdir, "run.log"), "w") as log:
+        subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT)
+    files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
+    acc = {}
+    for row in csv.DictReader(open(files[0])):
+        if row["Counter_Name"] != counter:
+            continue
+        for key in KERNELS:
+            name = row["Kernel_Name"]
+            # X is f32: the f64 instantiations are the same kernels applied to Y or to S (small), not X sweeps
+            if f"cmtfpls::{key}<float" in name and not (key == "contract_vec_kernel" and "<float, 2" in name):
+                acc.setdefault(key, []).append(float(row["Counter_Value"]) * 1024.0)
+    return acc
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    scratch = os.path.join(ROOT, "gpurun_out", "pmc")
+    fetch = one_pass("FETCH_SIZE", os.path.join(scratch, "fetch"))
+    write = one_pass("WRITE_SIZE", os.path.join(scratch, "write"))
+    kernels = {}
+    for key, passes in KERNELS.items():
+        if key not in fetch or key not in write:
+            continue
+        f = sum(fetch[key]) / len(fetch[key])
+        w = sum(write[key]) / len(write[key])
+        rec = {"fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
+               "dispatches": len(fetch[key])}
+        if passes:
+            rec["algorithmic_bytes"] = passes * XBYTES
+            rec["ratio"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes"]
+        kernels[key] = rec
+    doc = {"method": __doc__.split("\n\n")[1].replace("\n", " "), "workload": "cfg2 65536x128x128 f32, 1 GPU",
+           "command": "python3 tools/pmc_traffic.py", "kernels": kernels}
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps({k: round(v.get("ratio", 0), 4) for k, v in kernels.items()}))
+
+
+if __name__ == "__main__":
+    main()

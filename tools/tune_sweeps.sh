@@ -5,14 +5,14 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "ntst:-DCMTFPLS_NT_STORE=1" "ntld:-DCMTFPLS_NT_LOAD=1" "ntboth:-DCMTFPLS_NT_LOAD=1 -DCMTFPLS_NT_STORE=1"
-          "b1024u8:-DCMTFPLS_SWEEP_BLOCKS=1024 -DCMTFPLS_UNROLL=8" "b4096:-DCMTFPLS_SWEEP_BLOCKS=4096" "u8:-DCMTFPLS_UNROLL=8" "u2:-DCMTFPLS_UNROLL=2")
+VARIANTS=("base:" "cb2048:-DCMTFPLS_CONTRACT_BLOCKS=2048" "cb512:-DCMTFPLS_CONTRACT_BLOCKS=512" "ru4:-DCMTFPLS_ROW_UNROLL=4" "ru16:-DCMTFPLS_ROW_UNROLL=16"
+          "ntoff:-DCMTFPLS_NT_LOAD=0 -DCMTFPLS_NT_STORE=0")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
     name="${v%%:*}"; flags="${v#*:}"
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags \
-        "$SRC/runtime.hip" "$SRC/sweeps.hip" "$SRC/small.hip" "$SRC/rank1.hip" "$SRC/rank1_tensor.hip" "$SRC/xcov.hip" "$SRC/mttkrp.hip" -o "$OUT/libcmtfpls_$name.so" ) &
+        "$SRC/runtime.hip" "$SRC/sweeps.hip" "$SRC/small.hip" "$SRC/rank1.hip" "$SRC/rank1_tensor.hip" "$SRC/xcov.hip" "$SRC/mttkrp.hip" "$SRC/mixed.hip" -o "$OUT/libcmtfpls_$name.so" ) &
   done
   wait
   ls -la "$OUT"
@@ -20,6 +20,6 @@ else
   for v in "${VARIANTS[@]}"; do
     name="${v%%:*}"
     echo "=== variant $name"
-    CMTFPLS_LIB="$OUT/libcmtfpls_$name.so" python "$ROOT/tools/kernel_bench.py" --only sweeps 2>&1 | grep -v amdgpu.ids
+    CMTFPLS_LIB="$OUT/libcmtfpls_$name.so" python "$ROOT/tools/kernel_bench.py" --only sweeps "${@:2}" 2>&1 | grep -v amdgpu.ids
   done
 fi
