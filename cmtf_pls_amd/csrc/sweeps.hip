@@ -16,6 +16,7 @@ namespace cmtfpls {
 // mode-0 contraction / column statistics
 // ------------------------------------------------------------------------------------------
 constexpr int kContractU = 2;  // 16-byte column groups per thread
+constexpr int kYqChunk = 2048;  // rows of u = Y q a workgroup keeps in LDS at a time (YQ variants)
 
 struct ContractPlan {
   int vec;            // 1: vector kernel, 0: scalar kernel
@@ -80,7 +81,7 @@ __device__ __forceinline__ void rows_times_q(const double* __restrict__ Y, int l
 }
 
 // MODE 0: plain (NaN propagates, as np.einsum)  1: NaN -> 0  2: statistics (u == 1, NaN -> 0, count)
-// YQ: u is not read; u[i] = Y[i, :] . q is formed per workgroup in LDS (dynamic, rows_per_block doubles)
+// YQ: u is not read; u[i] = Y[i, :] . q is formed per workgroup in LDS, kYqChunk rows at a time
 template <typename T, int MODE, bool YQ>
 __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
@@ -93,7 +94,6 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
   const int64_t cbase = (int64_t)blockIdx.x * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
-  if (YQ) rows_times_q(Y, ldy, M, q, r0, r1, us);
   double acc[U][V];
   double cnt[U][V];
   bool ok[U];
@@ -104,6 +104,15 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     for (int e = 0; e < V; ++e) { acc[g][e] = 0.0; cnt[g][e] = 0.0; }
   }
   constexpr int RU = kUnroll;
+  // YQ: the workgroup's rows go through LDS in chunks of kYqChunk rows of u (16 KB), whatever rows_per_block is
+  const int64_t rend = r1;
+  for (int64_t rc0 = r0; rc0 < rend; rc0 += (YQ ? (int64_t)kYqChunk : rend - r0)) {
+  const int64_t r0 = rc0;                                                   // chunk = [r0, r1) below
+  const int64_t r1 = (YQ && rc0 + kYqChunk < rend) ? rc0 + kYqChunk : rend;
+  if (YQ) {
+    if (rc0 != (int64_t)blockIdx.y * rows_per_block) __syncthreads();       // the previous chunk's readers are done
+    rows_times_q(Y, ldy, M, q, r0, r1, us);
+  }
   int64_t r = r0;
   for (; r + RU <= r1; r += RU) {
     VT x[RU][U];
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
         }
       }
   }
+  }   // chunks
 #pragma unroll
   for (int g = 0; g < U; ++g)
     if (ok[g]) {
@@ -173,20 +183,27 @@ __global__ __launch_bounds__(kSweepThreads) void contract_narrow_kernel(
     const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
     double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block,
     const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q, int ncv, int RS) {
-  extern __shared__ double us[];                       // YQ: rows_per_block doubles
+  extern __shared__ double us[];                       // YQ: kYqChunk doubles
   constexpr int V = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
   __shared__ double red[kSweepThreads * V];             // [row lane][column] = RS x P <= 256 V doubles
   __shared__ double redc[(MODE == 2) ? kSweepThreads * V : 1];
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
-  if (YQ) rows_times_q(Y, ldy, M, q, r0, r1, us);
   const int cv = threadIdx.x % ncv, rl = threadIdx.x / ncv;
   const bool active = rl < RS;
   const int64_t c = (int64_t)cv * V;
   double acc[V], cnt[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { acc[e] = 0.0; cnt[e] = 0.0; }
+  const int64_t rend = r1;
+  for (int64_t rc0 = r0; rc0 < rend; rc0 += (YQ ? (int64_t)kYqChunk : rend - r0)) {   // chunks of u in LDS (YQ)
+  const int64_t r0 = rc0;
+  const int64_t r1 = (YQ && rc0 + kYqChunk < rend) ? rc0 + kYqChunk : rend;
+  if (YQ) {
+    if (rc0 != (int64_t)blockIdx.y * rows_per_block) __syncthreads();
+    rows_times_q(Y, ldy, M, q, r0, r1, us);
+  }
   if (active) {
     constexpr int RU = kUnroll;
     int64_t r = r0 + rl;
@@ -228,6 +245,9 @@ __global__ __launch_bounds__(kSweepThreads) void contract_narrow_kernel(
         }
       }
     }
+  }
+  }   // chunks
+  if (active) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       red[(int64_t)rl * P + c + e] = acc[e];
@@ -329,9 +349,9 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   const bool narrow = p.vec && ncv <= kSweepThreads / 2;          // at least two rows per workgroup pass
   const int RS = narrow ? kSweepThreads / ncv : 1;
   if (yq) {
-    // supported: vector shape, M <= 64 (one Y row per wavefront pass), the workgroup's u chunk within 64 KB of LDS
-    const size_t lds = (size_t)p.rows_per_block * sizeof(double);
-    if (!p.vec || M > 64 || lds > 48 * 1024 || MODE == 2) {
+    // supported: vector shape, M <= 64 (one Y row per wavefront pass)
+    const size_t lds = (size_t)kYqChunk * sizeof(double);
+    if (!p.vec || M > 64 || MODE == 2) {
       set_error("mode0_contract_yq: shape outside the fused form; form u = Y q with rowdot and use mode0_contract");
       return CMTFPLS_EUNSUPPORTED;
     }

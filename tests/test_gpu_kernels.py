@@ -514,3 +514,27 @@ def test_score_gram_more_than_64_responses_is_unsupported(be):
     X = dev(rng.normal(size=(20, 32)), torch.float32)
     Y = dev(rng.normal(size=(20, 65)))
     assert be.score_gram(X, 4, 8, dev(rng.normal(size=4)), dev(rng.normal(size=8)), None, be.empty(20), Y, be.empty(be.n_partials * 65)) is None
+
+
+@pytest.mark.parametrize("I,A,B", [(70000, 256, 256), (2_200_000, 2, 4)])
+def test_mode0_contract_yq_row_chunks(be, I, A, B):
+    """Workgroups whose row range exceeds one LDS chunk of u = Y q (2048 rows): the wide kernel at
+    70000 x 65536 (2188 rows per workgroup) and the narrow kernel at 2.2M x 8.  Data and the f64
+    reference are formed on the device (the tensors are 18 GB / 70 MB)."""
+    P, M = A * B, 16
+    g = torch.Generator(device="cuda:0").manual_seed(123)
+    X = torch.randn(I, P, device="cuda:0", dtype=torch.float32, generator=g)
+    Y = torch.randn(I, M, device="cuda:0", dtype=torch.float64, generator=g)
+    q = torch.randn(M, device="cuda:0", dtype=torch.float64, generator=g)
+    Z = be.mode0_contract_yq(X, Y, q, False, out=be.empty(P))
+    assert Z is not None
+    u = Y @ q
+    want = torch.zeros(P, device="cuda:0", dtype=torch.float64)
+    scale = torch.zeros(P, device="cuda:0", dtype=torch.float64)
+    step = 4096 if P > 1024 else 262144
+    for r in range(0, I, step):
+        xb = X[r:r + step].double()
+        want += xb.t() @ u[r:r + step]
+        scale += xb.abs().t() @ u[r:r + step].abs()
+    assert float(((Z - want).abs() / scale).max()) < 1e-13
+    assert torch.equal(be.mode0_contract(X, u, False), Z) or float(((be.mode0_contract(X, u, False) - Z).abs() / scale).max()) < 1e-15

@@ -72,7 +72,12 @@ def main():
     del X2
     rec("mode0_contract", lambda: be.mode0_contract(X, u, False, out=Z), xbytes)
     rec("mode0_contract masked", lambda: be.mode0_contract(X, u, True, out=Z), xbytes)
+    if args.M <= 64:
+        rec("mode0_contract_yq (u = Y q inside)", lambda: be.mode0_contract_yq(X, Y, q, False, out=Z), xbytes)
     rec("score", lambda: be.score(X, A, B, wa, wb, None, t), xbytes)
+    if args.M <= 64:
+        qpart = be.empty(be.n_partials * args.M)
+        rec("score_gram (+ Y^T t partials)", lambda: be.score_gram(X, A, B, wa, wb, None, t, Y, qpart), xbytes)
     rec("score masked", lambda: be.score(X, A, B, wa, wb, rowcnt, t), xbytes)
     rec("deflate (r+w)", lambda: be.deflate(X, A, B, tsmall, wa, wb), 2 * xbytes)
     rec("score_deflate fused (r+w)", lambda: be.score_deflate(X, A, B, wa, wb, None, t2), 2 * xbytes)
