@@ -46,6 +46,9 @@ SIGNATURES = {
     "cmtfpls_mttkrp_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, _P, c_int, _P]),
     "cmtfpls_score_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "cmtfpls_score_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "cmtfpls_deflate_contract_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "cmtfpls_deflate_contract_yq_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_size_t, _P]),
+    "cmtfpls_deflate_contract_yq_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_size_t, _P]),
     "cmtfpls_score_gram_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "cmtfpls_score_gram_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "cmtfpls_q_update_f64": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, _P, _P]),

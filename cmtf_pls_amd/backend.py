@@ -187,6 +187,20 @@ class HipBackend:
         _lib.check(self._fn("deflate", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(t), _ptr(wA), _ptr(wB), _ptr(part), self._stream()), "deflate")
         return self._close_partials(part)
 
+    def deflate_contract_yq(self, X2, A, B, t, wA, wB, Y: torch.Tensor, q: torch.Tensor, masked: bool,
+                            out: torch.Tensor) -> Optional[torch.Tensor]:
+        """K6 of one component fused with K1 of the next: X -= t (x) w in place, out = X_new x_0 (Y q); returns
+        the sum of squares of X_new (1 double) or None when the shape is outside the fused form."""
+        I, P = X2.shape
+        ws = self._workspace("deflate_contract", self.lib.cmtfpls_deflate_contract_workspace_bytes(I, P))
+        ssq = self.empty(1)
+        rc = self._fn("deflate_contract_yq", X2)(_ptr(X2), I, A, B, _ptr(t), _ptr(wA), _ptr(wB), _ptr(Y), Y.stride(0), Y.shape[1],
+                                                 _ptr(q), _ptr(out), int(masked), _ptr(ssq), _ptr(ws), ws.numel(), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "deflate_contract_yq")
+        return ssq
+
     def score_deflate(self, X2, A, B, wA, wB, rowcnt, out) -> Optional[torch.Tensor]:
         """Fused K3+K6; returns None when the row does not fit (caller then uses score + deflate)."""
         part = self.empty(self.n_partials)

@@ -174,6 +174,107 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     }
 }
 
+// Deflation of component a fused with the first contraction of component a+1 (tpls.py:109, then
+// tpls.py:80-83 of the next pass of the component loop): X[i,c] -= t[i] wA[c/B] wB[c%B] is written back
+// and the new value is contracted with the next u in the same sweep, so the first iteration of every
+// component but the first costs one X read less.  Thread layout of contract_vec_kernel (a thread owns
+// 2 x 16 B of columns: its wA / wB entries live in registers); the arithmetic per element is that of
+// deflate_kernel followed by contract_vec_kernel, bit for bit; also the sum of squares of the new X.
+template <typename T, int MODE, bool YQ>
+__global__ __launch_bounds__(kSweepThreads) void deflate_contract_kernel(
+    T* __restrict__ X, int64_t I, int64_t P, int B, const double* __restrict__ t,
+    const double* __restrict__ wA, const double* __restrict__ wB, const double* __restrict__ u,
+    double* __restrict__ part, double* __restrict__ ssq_part, int rows_per_block,
+    const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q) {
+  extern __shared__ double us[];
+  __shared__ double red[16];
+  constexpr int V = VecOf<T>::N;
+  constexpr int U = kContractU;
+  using VT = typename VecOf<T>::type;
+  const int64_t cbase = (int64_t)blockIdx.x * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
+  const int64_t rb0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t rend = (rb0 + rows_per_block < I) ? rb0 + rows_per_block : I;
+  double acc[U][V], wb[U][V], wa[U];
+  bool ok[U];
+#pragma unroll
+  for (int g = 0; g < U; ++g) {
+    const int64_t c = cbase + (int64_t)g * kSweepThreads * V;
+    ok[g] = c < P;
+    const int64_t cs = ok[g] ? c : 0;
+    wa[g] = wA[cs / B];                                  // B % V == 0: one j for the whole vector
+#pragma unroll
+    for (int e = 0; e < V; ++e) { acc[g][e] = 0.0; wb[g][e] = wB[cs % B + e]; }
+  }
+  double ssq = 0.0;
+  constexpr int RU = kUnroll;
+  for (int64_t rc0 = rb0; rc0 < rend; rc0 += (YQ ? (int64_t)kYqChunk : rend - rb0)) {
+    const int64_t r0 = rc0;
+    const int64_t r1 = (YQ && rc0 + kYqChunk < rend) ? rc0 + kYqChunk : rend;
+    if (YQ) {
+      if (rc0 != rb0) __syncthreads();
+      rows_times_q(Y, ldy, M, q, r0, r1, us);
+    }
+    int64_t r = r0;
+    for (; r + RU <= r1; r += RU) {
+      VT x[RU][U];
+      double uu[RU], tt[RU];
+#pragma unroll
+      for (int s = 0; s < RU; ++s) {
+        uu[s] = YQ ? us[r + s - r0] : u[r + s];
+        tt[s] = t[r + s];
+#pragma unroll
+        for (int g = 0; g < U; ++g)
+          if (ok[g]) x[s][g] = ld_stream(reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V));
+      }
+#pragma unroll
+      for (int s = 0; s < RU; ++s)
+#pragma unroll
+        for (int g = 0; g < U; ++g)
+          if (ok[g]) {
+            const double tw = tt[s] * wa[g];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const T nv = (T)fma(-tw, wb[g][e], (double)x[s][g].e[e]);
+              x[s][g].e[e] = nv;
+              const double d = (nv == nv) ? (double)nv : 0.0;          // NaN (missing) stays NaN, skipped in the norm
+              ssq = fma(d, d, ssq);
+              acc[g][e] = fma((MODE == 0) ? (double)nv : d, uu[s], acc[g][e]);
+            }
+            st_stream(reinterpret_cast<VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V), x[s][g]);
+          }
+    }
+    for (; r < r1; ++r) {
+      const double ur = YQ ? us[r - r0] : u[r];
+      const double tr = t[r];
+#pragma unroll
+      for (int g = 0; g < U; ++g)
+        if (ok[g]) {
+          VT x = ld_stream(reinterpret_cast<const VT*>(X + r * P + cbase + (int64_t)g * kSweepThreads * V));
+          const double tw = tr * wa[g];
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const T nv = (T)fma(-tw, wb[g][e], (double)x.e[e]);
+            x.e[e] = nv;
+            const double d = (nv == nv) ? (double)nv : 0.0;
+            ssq = fma(d, d, ssq);
+            acc[g][e] = fma((MODE == 0) ? (double)nv : d, ur, acc[g][e]);
+          }
+          st_stream(reinterpret_cast<VT*>(X + r * P + cbase + (int64_t)g * kSweepThreads * V), x);
+        }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < U; ++g)
+    if (ok[g]) {
+      const int64_t c = cbase + (int64_t)g * kSweepThreads * V;
+#pragma unroll
+      for (int e = 0; e < V; ++e) part[(int64_t)blockIdx.y * P + c + e] = acc[g][e];
+    }
+  __syncthreads();                                       // `us` / `red` are not in use any more
+  const double sblk = block_sum(ssq, red);
+  if (threadIdx.x == 0) ssq_part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = sblk;
+}
+
 // Narrow blocks (P <= 128 vectors of 16 B, e.g. the I x 512 matrix block of a coupled fit): one row
 // needs only ncv = P / V threads, so the workgroup's 256 threads take RS = 256 / ncv rows at a time
 // (thread = (row lane, column vector)) and the RS row lanes are added in index order through LDS.
@@ -373,6 +474,39 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   launch_reduce_rows(part, p.row_blocks, P, out, st);
   if (MODE == 2) launch_reduce_rows(cntpart, p.row_blocks, P, cnt_out, st);
   return check_launch("mode0_contract");
+}
+
+template <typename T>
+static int run_deflate_contract(T* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB,
+                                const double* Y, int ldy, int M, const double* q, double* Z, int masked, double* ssq,
+                                void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!X || !t || !wA || !wB || !Y || !q || !Z || !ssq || I <= 0 || A <= 0 || B <= 0 || M <= 0 || ldy < M) {
+    set_error("deflate_contract_yq: bad argument");
+    return CMTFPLS_EINVAL;
+  }
+  const int64_t P = (int64_t)A * B;
+  constexpr int Vt = 16 / (int)sizeof(T);
+  const ContractPlan p = plan_contract(I, P, (int)sizeof(T));
+  if (!p.vec || (B % Vt) != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || M > 64) {
+    set_error("deflate_contract_yq: shape outside the fused form; use deflate, then mode0_contract");
+    return CMTFPLS_EUNSUPPORTED;
+  }
+  const size_t nss = (size_t)p.col_tiles * p.row_blocks;
+  const size_t need = ((size_t)p.row_blocks * (size_t)P + nss) * sizeof(double);
+  if (!ws || ws_bytes < need) { set_error("deflate_contract_yq: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  double* part = static_cast<double*>(ws);
+  double* sspart = part + (size_t)p.row_blocks * P;
+  const dim3 grid(p.col_tiles, p.row_blocks);
+  const size_t lds = (size_t)kYqChunk * sizeof(double);
+  if (masked)
+    hipLaunchKernelGGL((deflate_contract_kernel<T, 1, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, B, t, wA, wB, nullptr,
+                       part, sspart, p.rows_per_block, Y, ldy, M, q);
+  else
+    hipLaunchKernelGGL((deflate_contract_kernel<T, 0, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, B, t, wA, wB, nullptr,
+                       part, sspart, p.rows_per_block, Y, ldy, M, q);
+  launch_reduce_rows(part, p.row_blocks, P, Z, st);
+  launch_reduce_rows(sspart, (int)nss, 1, ssq, st);
+  return check_launch("deflate_contract_yq");
 }
 
 __device__ __forceinline__ void stage_loadings(double* sA, double* sB, const double* __restrict__ wA,
@@ -833,6 +967,22 @@ int cmtfpls_mode0_contract_yq_f64(const double* X, int64_t I, int64_t P, const d
                                   double* Z, int masked, void* ws, size_t n, void* s) {
   return masked ? run_contract<double, 1>(X, I, P, nullptr, Z, nullptr, ws, n, (hipStream_t)s, Y, ldy, M, q)
                 : run_contract<double, 0>(X, I, P, nullptr, Z, nullptr, ws, n, (hipStream_t)s, Y, ldy, M, q);
+}
+size_t cmtfpls_deflate_contract_workspace_bytes(int64_t I, int64_t P) {
+  if (I <= 0 || P <= 0) return 0;
+  const ContractPlan a = plan_contract(I, P, 4), b = plan_contract(I, P, 8);
+  const size_t na = (size_t)a.row_blocks * ((size_t)P + a.col_tiles), nb = (size_t)b.row_blocks * ((size_t)P + b.col_tiles);
+  return (na > nb ? na : nb) * sizeof(double);
+}
+int cmtfpls_deflate_contract_yq_f32(float* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB,
+                                    const double* Y, int ldy, int M, const double* q, double* Z, int masked, double* ssq,
+                                    void* ws, size_t n, void* s) {
+  return run_deflate_contract<float>(X, I, A, B, t, wA, wB, Y, ldy, M, q, Z, masked, ssq, ws, n, (hipStream_t)s);
+}
+int cmtfpls_deflate_contract_yq_f64(double* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB,
+                                    const double* Y, int ldy, int M, const double* q, double* Z, int masked, double* ssq,
+                                    void* ws, size_t n, void* s) {
+  return run_deflate_contract<double>(X, I, A, B, t, wA, wB, Y, ldy, M, q, Z, masked, ssq, ws, n, (hipStream_t)s);
 }
 int cmtfpls_score_gram_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt,
                            double* t, const double* Y, int ldy, int M, double* qpart, void* s) {

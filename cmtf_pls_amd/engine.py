@@ -324,6 +324,8 @@ class FitRun:
         # dq^T (Y^T Y) dq.  Other shapes keep the separate gram_tn / normalize / rowdot launches.
         # Coupled blocks: normalize(Y^T mean_b t_b) = normalize(sum_b Y^T t_b), so every block's score kernel
         # adds its partial rows and the averaged score itself is only formed once per component.
+        self._pending = None                      # (component, [ssq per block..., ssq of Y]) still on the device
+        self._z_ready = False                     # Zs already hold X x_0 u_0 of the component about to start
         self._fused = (algorithm == "direct" and M <= 64
                        and all(hasattr(be, f) for f in ("mode0_contract_yq", "score_gram", "q_update")))
         if self._fused:
@@ -560,20 +562,25 @@ class FitRun:
             else:
                 be.q_update(q_new, self.qpart, normalize=True, G=self.Gy, q_prev=q_cur, du2=self.status[0:1], nparts=nparts)
 
+        # the previous component's deflation already produced this contraction (see _finish_fused)
+        have_z = self._z_ready and it == 0
+        self._z_ready = False
         first = True
         while True:
             budgets = tuple(self.sq_budget)
             if not sharded:
                 def whole():
                     if first:
-                        seg_contract()
+                        if not have_z:
+                            seg_contract()
                         seg_colscale()
                     seg_loadings_scores()
                     seg_y_update()
-                self._run(("fiter", par, budgets, first), whole)
+                self._run(("fiter", par, budgets, first, have_z), whole)
             else:
                 if first:
-                    self._run(("fcontract", par), seg_contract)
+                    if not have_z:
+                        self._run(("fcontract", par), seg_contract)
                     for b in range(len(self.blocks)):
                         comm.allreduce(self.Zs[b])
                     seg_colscale()
@@ -630,8 +637,11 @@ class FitRun:
             else:
                 for m, d in enumerate(blk.shape[1:]):
                     blk.loadings[m][:, a].copy_(self.fac[b][m, :d])
-            if self.algorithm == "direct":
+            if self.algorithm == "direct" and not self._fused:
                 ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
+        if self.algorithm == "direct" and self._fused:
+            self._finish_fused(a)
+            return
         # inner regression: coef_[:, a] = lstsq(T, u) with columns > a still zero (tpls.py:110-112)
         Ta = self.T[:, : a + 1]
         G = be.gram_tn(Ta, Ta)
@@ -650,7 +660,65 @@ class FitRun:
         comm.allreduce(ssqy)
         self.r2y[a] = 1.0 - float(ssqy.item()) / self.ssqy0                      # tpls.py:118-120
 
+    def _finish_fused(self, a: int) -> None:
+        """Tail of finish_component on the fused direct path.  The inner regression and the Y deflation
+        (tpls.py:110-113) depend only on T and u, so they run BEFORE the X deflation (tpls.py:109); the X
+        deflation can then be fused with the first contraction of component a+1 (u_0 = Y_new[:, 0] is known):
+        one X read less per component.  The deflated norms behind R2X / R2Y (tpls.py:115-120) stay on the
+        device and ride in the NEXT component's packed read-back (or in result()), so a component costs one
+        host synchronisation here instead of two."""
+        be, comm = self.eng.be, self.eng.comm
+        k = a + 1
+        Ta = self.T[:, :k]
+        G = be.gram_tn(Ta, Ta)
+        g = be.gram_tn(Ta, self.u)
+        pend = self._pending
+        packed = torch.cat([G.reshape(-1), g.reshape(-1)] + ([s.reshape(-1) for s in pend[1]] if pend else []))
+        comm.allreduce(packed)
+        host = packed.cpu().numpy()
+        Gh, gh = host[: k * k].reshape(k, k), host[k * k: k * k + k]
+        bh = np.linalg.lstsq(Gh, gh, rcond=None)[0]                              # tpls.py:110-112
+        self.coef[:k, a] = bh
+        if pend:
+            self._book_r2(pend[0], host[k * k + k:])
+        b_dev = torch.from_numpy(np.ascontiguousarray(bh)).to(self.Y.device)
+        ssqy = be.y_deflate(self.Y, self.T, k, b_dev, self.q)                    # tpls.py:113
+        ssqs = []
+        self._z_ready = False
+        if k < self.R:
+            # u_0 of the next component is the first column of the deflated Y = Y e_0 (tpls.py:78)
+            q0 = self.qbuf[0]
+            q0.zero_()
+            q0[0] = 1.0
+            ready = True
+            for b, blk in enumerate(self.blocks):
+                s_b = be.deflate_contract_yq(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b], self.Y, q0,
+                                             blk.has_miss, out=self.Zs[b])
+                if s_b is None:                                                  # shape outside the fused form
+                    s_b = be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b])
+                    ready = False
+                ssqs.append(s_b)
+            self._z_ready = ready
+        else:
+            for b, blk in enumerate(self.blocks):
+                ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
+        self._pending = (a, ssqs + [ssqy])
+
+    def _book_r2(self, a: int, vals) -> None:
+        for b, blk in enumerate(self.blocks):
+            blk.r2x[a] = 1.0 - float(vals[b]) / blk.ssq0                         # tpls.py:115-117
+        self.r2y[a] = 1.0 - float(vals[len(self.blocks)]) / self.ssqy0           # tpls.py:118-120
+
+    def _flush_pending(self) -> None:
+        if self._pending:
+            a, tens = self._pending
+            packed = torch.cat([s.reshape(-1) for s in tens])
+            self.eng.comm.allreduce(packed)
+            self._book_r2(a, packed.cpu().numpy())
+            self._pending = None
+
     def result(self) -> FitState:
+        self._flush_pending()
         return FitState(coupled=self.coupled, n_components=self.R, blocks=self.blocks, T=self.T, U=self.U, Q=self.Q,
                         coef=self.coef, r2y=self.r2y, y_mean=self.y_mean, n_iter=self.n_iter,
                         n_samples_total=self.n_total)

@@ -143,6 +143,19 @@ int cmtfpls_score_f32(const float* X, int64_t I, int A, int B, const double* wA,
 int cmtfpls_score_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB,
                       const double* rowcnt, double* t, void* stream);
 
+/* Deflation of one component fused with the first contraction of the next (tpls.py:109 followed by
+ * tpls.py:80-83 of the next pass of the component loop): X is deflated in place exactly as
+ * cmtfpls_deflate_* does, and in the same sweep Z[c] = sum_i X_new[i,c] * (Y[i,:] . q) and
+ * ssq[0] = sum of squares of the observed entries of X_new (R2X numerator) are formed.  One read + one
+ * write of X instead of read + write + read.  Vector shapes with B % (16/sizeof(T)) == 0 and M <= 64
+ * only (CMTFPLS_EUNSUPPORTED otherwise: deflate, then mode0_contract). */
+size_t cmtfpls_deflate_contract_workspace_bytes(int64_t I, int64_t P);
+int cmtfpls_deflate_contract_yq_f32(float* X, int64_t I, int A, int B, const double* t, const double* wA,
+                                    const double* wB, const double* Y, int ldy, int M, const double* q, double* Z,
+                                    int masked, double* ssq, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_deflate_contract_yq_f64(double* X, int64_t I, int A, int B, const double* t, const double* wA,
+                                    const double* wB, const double* Y, int ldy, int M, const double* q, double* Z,
+                                    int masked, double* ssq, void* ws, size_t ws_bytes, void* stream);
 /* score + the partial sums of Y^T t (tpls.py:100, `Y.T @ X_scores`) of every workgroup's rows:
  * qpart is (cmtfpls_sweep_partials() x M) row-major; cmtfpls_q_update_f64 adds the rows in index order.
  * M <= 64 (CMTFPLS_EUNSUPPORTED otherwise: use score + gram_tn). */

@@ -51,6 +51,13 @@ class NumpyBackend:
             return None        # stands for "shape outside the fused form": the engine must fall back
         return self.mode0_contract(X2, Y @ q, masked, out=out)
 
+    def deflate_contract_yq(self, X2, A, B, t, wA, wB, Y, q, masked, out):
+        if X2.shape[1] % 2 == 1:
+            return None
+        ssq = self.deflate(X2, A, B, t, wA, wB)
+        self.mode0_contract(X2, Y @ q, masked, out=out)
+        return ssq
+
     def score_gram(self, X2, A, B, wA, wB, rowcnt, out, Y, qpart):
         if Y.shape[1] > 64:
             return None

@@ -538,3 +538,40 @@ def test_mode0_contract_yq_row_chunks(be, I, A, B):
         scale += xb.abs().t() @ u[r:r + step].abs()
     assert float(((Z - want).abs() / scale).max()) < 1e-13
     assert torch.equal(be.mode0_contract(X, u, False), Z) or float(((be.mode0_contract(X, u, False) - Z).abs() / scale).max()) < 1e-15
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("shape,M", [((37, 10, 8), 4), ((300, 16, 16), 16), ((1000, 16, 64), 17), ((50, 128, 128), 33),
+                                     ((2500, 2, 4), 3)])
+def test_deflate_contract_yq(be, shape, M, dt, masked):
+    """tpls.py:109 fused with tpls.py:80-83 of the next component: bit-identical to deflate followed by
+    mode0_contract_yq on the deflated X; the sum of squares equals the deflate kernel's to rounding."""
+    I, A, B = shape
+    x = make_x(shape, dt, nan_frac=0.2 if masked else 0.0, seed=97)
+    rng = np.random.default_rng(98)
+    wa, wb = rng.normal(size=A), rng.normal(size=B)
+    wa, wb = dev(wa / np.linalg.norm(wa)), dev(wb / np.linalg.norm(wb))
+    t, y, q = dev(rng.normal(size=I)), dev(rng.normal(size=(I, M))), dev(rng.normal(size=M))
+    X1, X2 = dev(x, TDT[dt]), dev(x, TDT[dt])
+    Z1 = be.empty(A * B)
+    ssq1 = be.deflate_contract_yq(X1, A, B, t, wa, wb, y, q, masked, out=Z1)
+    assert ssq1 is not None
+    ssq2 = be.deflate(X2, A, B, t, wa, wb)
+    Z2 = be.mode0_contract_yq(X2, y, q, masked, out=be.empty(A * B))
+    assert torch.equal(X1.view(torch.uint8), X2.view(torch.uint8))             # same bits, NaNs included
+    assert torch.equal(torch.isnan(Z1), torch.isnan(Z2))
+    np.testing.assert_allclose(np.nan_to_num(host(Z1)), np.nan_to_num(host(Z2)), rtol=1e-12, atol=1e-12 * float(np.nanmax(np.abs(host(Z2))) + 1e-300))
+    np.testing.assert_allclose(host(ssq1)[0], host(ssq2)[0], rtol=1e-12)
+    want = x - np.outer(host(t), np.kron(host(wa), host(wb)))
+    if dt == "f32":
+        want = want.astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(np.nan_to_num(host(X1).astype(np.float64)), np.nan_to_num(want), rtol=3e-7 if dt == "f32" else 1e-13, atol=1e-10)
+
+
+def test_deflate_contract_yq_unsupported(be):
+    rng = np.random.default_rng(99)
+    X = dev(rng.normal(size=(40, 7 * 9)), torch.float32)
+    r = be.deflate_contract_yq(X, 7, 9, dev(rng.normal(size=40)), dev(rng.normal(size=7)), dev(rng.normal(size=9)),
+                               dev(rng.normal(size=(40, 3))), dev(rng.normal(size=3)), False, out=be.empty(63))
+    assert r is None
