@@ -139,6 +139,13 @@ class HipBackend:
         _lib.check(fn(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
         return S
 
+    def s_downdate(self, S: torch.Tensor, A: int, B: int, ya: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
+                   q: torch.Tensor, v: torch.Tensor) -> None:
+        """S -= ya w^T + q v^T, w = kron(wA, wB): S = Y^T X_(0) carried across one deflation."""
+        assert S.is_contiguous() and S.shape[1] == A * B
+        _lib.check(self.lib.cmtfpls_s_downdate_f64(_ptr(S), S.shape[0], A, B, _ptr(ya), _ptr(wA), _ptr(wB), _ptr(q), _ptr(v),
+                                                   self._stream()), "s_downdate")
+
     def quadform(self, G: torch.Tensor, q: torch.Tensor, q_old: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.check(self.lib.cmtfpls_quadform_f64(_ptr(G), G.shape[0], _ptr(q), _ptr(q_old), _ptr(out), self._stream()), "quadform")
         return out

@@ -219,6 +219,25 @@ __global__ __launch_bounds__(1024) void q_update_kernel(const double* __restrict
   }
 }
 
+// Down-date of the cross-covariance S = Y^T X_(0) (M x P) across one deflation (tpls.py:109,113):
+//   X+ = X - t w^T,  Y+ = Y - yhat q^T   =>   S+ = S - (Y^T t) w^T - q (X+^T yhat)^T
+// with w[c] = wA[c / B] wB[c % B] formed on the fly.  One thread per column, M rows each.
+__global__ __launch_bounds__(256) void s_downdate_kernel(double* __restrict__ S, int M, int64_t P, int B,
+                                                        const double* __restrict__ ya, const double* __restrict__ wA,
+                                                        const double* __restrict__ wB, const double* __restrict__ q,
+                                                        const double* __restrict__ v) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= P) return;
+  const double w = wA[c / B] * wB[c % B];
+  const double vc = v[c];
+  for (int m = 0; m < M; ++m) {
+    double sv = S[(int64_t)m * P + c];
+    sv = fma(-ya[m], w, sv);
+    sv = fma(-q[m], vc, sv);
+    S[(int64_t)m * P + c] = sv;
+  }
+}
+
 __global__ __launch_bounds__(256) void colscale_kernel(double* __restrict__ Z, int64_t P, const double* __restrict__ cnt, double n_samples) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c < P) Z[c] = (cnt[c] > 0.0) ? Z[c] / cnt[c] * n_samples : 0.0;
@@ -311,6 +330,14 @@ int cmtfpls_q_update_f64(const double* qpart, int nblk, int M, double* q, int no
   if (M > 64) { set_error("q_update: more than 64 responses; use gram_tn + normalize + rowdot"); return CMTFPLS_EUNSUPPORTED; }
   hipLaunchKernelGGL(q_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, qpart, nblk, M, q, normalize, G, q_prev, du2);
   return check_launch("q_update");
+}
+
+int cmtfpls_s_downdate_f64(double* S, int M, int A, int B, const double* ya, const double* wA, const double* wB,
+                           const double* q, const double* v, void* stream) {
+  if (!S || !ya || !wA || !wB || !q || !v || M <= 0 || A <= 0 || B <= 0) { set_error("s_downdate: bad argument"); return CMTFPLS_EINVAL; }
+  const int64_t P = (int64_t)A * B;
+  hipLaunchKernelGGL(s_downdate_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, M, P, B, ya, wA, wB, q, v);
+  return check_launch("s_downdate");
 }
 
 int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_samples, void* stream) {

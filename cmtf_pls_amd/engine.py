@@ -346,6 +346,16 @@ class FitRun:
             self.Tq = be.empty(nb, M)
             self.qc = be.empty(M)
             self.qn = self.Tq[0] if (nb == 1 and not coupled) else be.empty(M)
+            # S is carried across a deflation instead of rebuilt when no block has missing values:
+            # S+ = S - (Y^T t) w^T - q (X+^T yhat)^T, with X+^T yhat formed inside the deflation sweep
+            self._s_carry = (not any(blk.has_miss for blk in self.blocks)
+                             and all(hasattr(be, f) for f in ("s_downdate", "deflate_contract_yq")))
+            self._s_ready = False
+            if self._s_carry:
+                self.yhat = be.empty(I, 1)
+                self.one = be.empty(1)
+                self.one.fill_(1.0)
+                self.vs = [be.empty(blk.A * blk.B) for blk in self.blocks]
 
     def start_component(self, a: int) -> None:
         self._executed = 0
@@ -361,12 +371,15 @@ class FitRun:
                 comm.allreduce(self.Gy)
             return
         for b, blk in enumerate(self.blocks):
+            if self._s_ready:
+                break                                             # S was down-dated by the previous finish_component
             be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b], mixed=self.mixed)
             comm.allreduce(self.S[b])
             if blk.has_miss:
                 torch.mul(self.Y, self.rowscale[b][:, None], out=self.Yw)
                 be.xcov(self.X2[b], self.Yw, True, out=self.S2[b], mixed=self.mixed)
                 comm.allreduce(self.S2[b])
+        self._s_ready = False
         be.gram_tn(self.Y, self.Y, out=self.Gy)
         comm.allreduce(self.Gy)
         self.qc.zero_()
@@ -599,6 +612,9 @@ class FitRun:
         be, comm = self.eng.be, self.eng.comm
         self.n_iter.append(self._executed)
         ssqs = []
+        if self.algorithm == "xcov" and self._s_carry:
+            self._finish_xcov_carry(a)
+            return
         if self.algorithm == "xcov":
             # the final score (tpls.py:92-99 with the converged loadings) and the deflation (tpls.py:109)
             # are the only other passes over X: fused into one read + one write when there is one block
@@ -699,6 +715,73 @@ class FitRun:
                     ready = False
                 ssqs.append(s_b)
             self._z_ready = ready
+        else:
+            for b, blk in enumerate(self.blocks):
+                ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
+        self._pending = (a, ssqs + [ssqy])
+
+    def _store_component(self, a: int) -> None:
+        self.T[:, a].copy_(self.t)
+        self.U[:, a].copy_(self.u)
+        self.Q[:, a].copy_(self.q)
+        for b, blk in enumerate(self.blocks):
+            if len(blk.shape) == 2:
+                blk.loadings[0][:, a].copy_(self.wB[b])
+            elif len(blk.shape) == 3:
+                blk.loadings[0][:, a].copy_(self.wA[b])
+                blk.loadings[1][:, a].copy_(self.wB[b])
+            else:
+                for m, d in enumerate(blk.shape[1:]):
+                    blk.loadings[m][:, a].copy_(self.fac[b][m, :d])
+
+    def _finish_xcov_carry(self, a: int) -> None:
+        """finish_component of the xcov algorithm when S is carried across the deflation.  Passes over X:
+        the final score (read; tpls.py:92-99 with the converged loadings) and the deflation (read + write;
+        tpls.py:109), which also forms v = X+^T yhat for the down-date of S -- no S build on the matrix
+        cores for the next component.  R2 bookkeeping is deferred as in _finish_fused."""
+        be, comm = self.eng.be, self.eng.comm
+        self.q = self.qc
+        for b, blk in enumerate(self.blocks):
+            be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Ts[b])
+        if self.t.data_ptr() != self.Ts.data_ptr():
+            be.scores_mean(self.Ts, self.t)                                      # cmtf.py:120
+        be.rowdot(self.Y, self.q, self.u, None)                                  # u = Y q (tpls.py:102)
+        self._store_component(a)
+        k = a + 1
+        Ta = self.T[:, :k]
+        G = be.gram_tn(Ta, Ta)
+        g = be.gram_tn(Ta, self.u)
+        ya = be.gram_tn(self.Y, self.t).reshape(-1)                              # Y^T t with the not yet deflated Y
+        pend = self._pending
+        packed = torch.cat([G.reshape(-1), g.reshape(-1), ya] + ([s.reshape(-1) for s in pend[1]] if pend else []))
+        comm.allreduce(packed)
+        host = packed.cpu().numpy()
+        M = self.M
+        Gh, gh = host[: k * k].reshape(k, k), host[k * k: k * k + k]
+        bh = np.linalg.lstsq(Gh, gh, rcond=None)[0]                              # tpls.py:110-112
+        self.coef[:k, a] = bh
+        if pend:
+            self._book_r2(pend[0], host[k * k + k + M:])
+        b_dev = torch.from_numpy(np.ascontiguousarray(bh)).to(self.Y.device)
+        ya_g = packed[k * k + k: k * k + k + M]                                  # all-reduced Y^T t
+        ssqs = []
+        if k < self.R:
+            be.rowdot(Ta, b_dev, self.yhat.view(-1), None)                       # yhat = T b (what Y is deflated by)
+        ssqy = be.y_deflate(self.Y, self.T, k, b_dev, self.q)                    # tpls.py:113
+        if k < self.R:
+            carried = True
+            for b, blk in enumerate(self.blocks):
+                s_b = be.deflate_contract_yq(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b], self.yhat, self.one,
+                                             False, out=self.vs[b])
+                if s_b is None:                                                  # shape outside the fused form
+                    s_b = be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b])
+                    carried = False
+                ssqs.append(s_b)
+            if carried:
+                for b, blk in enumerate(self.blocks):
+                    comm.allreduce(self.vs[b])
+                    be.s_downdate(self.S[b], blk.A, blk.B, ya_g, self.wA[b], self.wB[b], self.q, self.vs[b])
+            self._s_ready = carried
         else:
             for b, blk in enumerate(self.blocks):
                 ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109

@@ -115,6 +115,12 @@ int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int 
 int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
                      int masked, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream);
+/* S carried across one deflation instead of rebuilt (tpls.py:109 and :113 applied to S = Y^T X_(0)):
+ * with X+ = X - t w^T and Y+ = Y - yhat q^T (yhat = T b, the inner-regression prediction),
+ *   S+ = S - ya w^T - q v^T,   ya = Y^T t (M, taken before Y is deflated),  v = X+^T yhat (P, from
+ * cmtfpls_deflate_contract_yq_* with Y = yhat as an I x 1 matrix and q = [1]),  w[c] = wA[c/B] wB[c%B]. */
+int cmtfpls_s_downdate_f64(double* S, int M, int A, int B, const double* ya, const double* wA, const double* wB,
+                           const double* q, const double* v, void* stream);
 /* Opt-in mixed-precision forms of xcov and mttkrp for f32-stored X: v_mfma_f32_16x16x4_f32 (half the
  * matrix cycles of the f64 form, HBM-bound instead of matrix-pipe-bound).  X is exact; the other
  * operand is rounded once to f32; f32 accumulation only inside chains of 64 rows (xcov) / 256 columns

@@ -90,6 +90,9 @@ class NumpyBackend:
             return out
         return S
 
+    def s_downdate(self, S, A, B, ya, wA, wB, q, v):
+        S -= torch.outer(ya.reshape(-1), torch.from_numpy(self._w(wA, wB))) + torch.outer(q, v)
+
     def quadform(self, G, q, q_old, out):
         d = q - q_old
         out[0] = float(d @ G @ d)
