@@ -9,10 +9,12 @@
 namespace cmtfpls {
 
 constexpr int kWave = 64;
-// Every X sweep (center / score / deflate / score_deflate) is launched with exactly this many
-// workgroups, grid-striding over rows; 2048 x 256 threads = 8 workgroups on each of the 256 CUs.
+// Every row-wise X sweep (center / score / deflate / score_deflate) is launched with exactly this many
+// workgroups, grid-striding over rows.  512 x 256 threads = 2 workgroups = 8 rows in flight on each of
+// the 256 CUs: measured best (6.9 TB/s against 6.6 TB/s with 2048; 256 is too few to cover the HBM
+// latency) -- fewer concurrent row streams keep more DRAM pages open (profiles/r01p_tune_sweeps.txt).
 #ifndef CMTFPLS_SWEEP_BLOCKS
-#define CMTFPLS_SWEEP_BLOCKS 2048
+#define CMTFPLS_SWEEP_BLOCKS 512
 #endif
 #ifndef CMTFPLS_UNROLL
 #define CMTFPLS_UNROLL 4          // rows in flight per thread in the contraction

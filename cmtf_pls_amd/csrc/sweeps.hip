@@ -660,6 +660,66 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
   }
 }
 
+// Deflation with one WORKGROUP per row (vector shapes, rows of up to MAXT * V * NV elements): the whole
+// row is read (NV 16-byte loads per lane in flight), updated and written back by the same workgroup, so
+// HBM sees long read bursts followed by long write bursts of the same pages.  Measured against the
+// wavefront-per-row kernel above: 1.57 vs 1.60 ms at 65536 x 128 x 128 f32, 3.15 vs 3.27 ms at
+// 32768 x 256 x 256 (profiles/r01p_tune_sweeps.txt).  Same arithmetic, bit for bit.
+template <typename T, int NV, int MAXT, bool KC>
+__global__ __launch_bounds__(MAXT) void deflate_rows_kernel(
+    T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ t,
+    const double* __restrict__ wA, const double* __restrict__ wB, double* __restrict__ ssq_part) {
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  double* sA = lds;
+  double* sB = lds + ((A + 1) & ~1);
+  stage_loadings(sA, sB, wA, wB, A, B);
+  constexpr int V = VecOf<T>::N;
+  using VT = Pack<T, V>;
+  const unsigned P = (unsigned)A * (unsigned)B;
+  constexpr unsigned stride = (unsigned)MAXT * V;
+  const unsigned c0 = threadIdx.x * V;
+  const KronWalk w0(c0, stride, B);
+  // KC: the stride is a multiple of B, so a lane's vectors all have the same k = c % B: its wB entries
+  // stay in registers and j advances by stride / B (no LDS read per element, no index walk)
+  const int dj = KC ? (int)(stride / (unsigned)B) : 0;
+  double wbv[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) wbv[e] = KC ? sB[(w0.k + e < B) ? w0.k + e : 0] : 0.0;
+  double ssq = 0.0;
+  for (int64_t row = blockIdx.x; row < I; row += gridDim.x) {
+    T* __restrict__ xr = X + row * (int64_t)P;
+    const double ti = t[row];
+    VT x[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const unsigned c = c0 + n * stride;
+      x[n] = ld_stream(reinterpret_cast<const VT*>(xr + ((c < P) ? c : 0)));        // clamped: no branch around the load
+    }
+    KronWalk w = w0;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const unsigned c = c0 + n * stride;
+      if (c < P) {
+        const double tw = ti * sA[KC ? w0.j + n * dj : w.j];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const T nv = (T)fma(-tw, KC ? wbv[e] : sB[w.k + e], (double)x[n].e[e]);
+          x[n].e[e] = nv;
+          const double d = (nv == nv) ? (double)nv : 0.0;
+          ssq = fma(d, d, ssq);
+        }
+        st_stream(reinterpret_cast<VT*>(xr + c), x[n]);
+      }
+      if (!KC) w.next();
+    }
+  }
+  if (ssq_part) {
+    const double sblk = block_sum(ssq, red);
+    if (threadIdx.x == 0) ssq_part[blockIdx.x] = sblk;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // center: X[i,c] -= mean[c]; per-row observation counts; sum of squares     wavefront per row
 // ------------------------------------------------------------------------------------------
@@ -717,7 +777,7 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
   constexpr bool FULL = MODE == 2;   // and the workgroup covers the row exactly: no column guards
   constexpr int V = VEC ? VecOf<T>::N : 1;
   using VT = Pack<T, V>;
-  constexpr int NL = (MAXT > 256) ? NV / 2 : 0;   // vectors per lane parked in LDS
+  constexpr int NL = (MAXT > 256 && NV >= 16) ? NV / 2 : 0;   // vectors per lane parked in LDS
   constexpr int NR = NV - NL;                     // vectors per lane held in registers
   constexpr int G = 4;                            // parked vectors are streamed G loads at a time
   static_assert(NL % G == 0, "parked vectors come in groups of G");
@@ -875,6 +935,30 @@ static int run_deflate(T* X, int64_t I, int A, int B, const double* t, const dou
   const size_t lds = loadings_lds_bytes(A, B);
   if (lds > kMaxLoadingsLds) { set_error("deflate: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
   const dim3 g(kSweepBlocks), b(kSweepThreads);
+#ifndef CMTFPLS_DEFLATE_ROWS
+#define CMTFPLS_DEFLATE_ROWS 1
+#endif
+  if (CMTFPLS_DEFLATE_ROWS && vec_ok(X, B)) {
+    const int64_t P = (int64_t)A * B;
+    constexpr int V = VecOf<T>::N;
+    const bool kc = ((1024 * V) % B) == 0;
+#ifndef CMTFPLS_DEFLATE_ROWS_PAD
+#define CMTFPLS_DEFLATE_ROWS_PAD 81920
+#endif
+    // (shadows the outer lds) > half of the CU's 160 KB of LDS: ONE workgroup (one row) per CU at a time --
+    // with two, the read/write streams of the rows interleave at the HBM and the sweep is 4 % slower
+    const size_t lds = loadings_lds_bytes(A, B) + CMTFPLS_DEFLATE_ROWS_PAD;
+    if (P > (int64_t)256 * V * 4 && P <= (int64_t)1024 * V * 4) {
+      if (kc) hipLaunchKernelGGL((deflate_rows_kernel<T, 4, 1024, true>), g, dim3(1024), lds, st, X, I, A, B, t, wA, wB, ssq_part);
+      else hipLaunchKernelGGL((deflate_rows_kernel<T, 4, 1024, false>), g, dim3(1024), lds, st, X, I, A, B, t, wA, wB, ssq_part);
+      return check_launch("deflate");
+    }
+    if (P > (int64_t)1024 * V * 4 && P <= (int64_t)1024 * V * 16) {
+      if (kc) hipLaunchKernelGGL((deflate_rows_kernel<T, 16, 1024, true>), g, dim3(1024), lds, st, X, I, A, B, t, wA, wB, ssq_part);
+      else hipLaunchKernelGGL((deflate_rows_kernel<T, 16, 1024, false>), g, dim3(1024), lds, st, X, I, A, B, t, wA, wB, ssq_part);
+      return check_launch("deflate");
+    }
+  }
   if (vec_ok(X, B)) hipLaunchKernelGGL((deflate_kernel<T, true>), g, b, lds, st, X, I, A, B, t, wA, wB, ssq_part);
   else hipLaunchKernelGGL((deflate_kernel<T, false>), g, b, lds, st, X, I, A, B, t, wA, wB, ssq_part);
   return check_launch("deflate");
@@ -894,10 +978,10 @@ template <typename T, bool MASKED, bool VEC, int KC>
 static void launch_sd(int nv, int threads, size_t lds, hipStream_t st, T* X, int64_t I, int A, int B,
                       const double* wA, const double* wB, const double* rowcnt, double* t, double* ssq_part) {
   const dim3 g(kSweepBlocks), b(threads);
-  if (threads > 256) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 1024, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  if (threads > 256 && nv == 4) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 4, 1024, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else if (threads > 256) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 1024, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
   else if (nv == 1) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 1, 256, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else if (nv == 4) hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 4, 256, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
-  else hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 16, 256, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
+  else hipLaunchKernelGGL((score_deflate_kernel<T, MASKED, VEC, 4, 256, KC>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);
 }
 
 template <typename T>
@@ -909,11 +993,13 @@ static int run_score_deflate(T* X, int64_t I, int A, int B, const double* wA, co
   const bool v = vec_ok(X, B), m = rowcnt != nullptr;
   const int V = v ? VecOf<T>::N : 1;
   const int64_t P = (int64_t)A * B;
-  // 256 threads hold up to 256*V*16 elements of a row in registers; longer rows take 1024 threads
+  // rows of up to 256*V*4 elements: 256 threads, 1 or 4 vectors per lane; up to 1024*V*4: 1024 threads x 4
+  // vectors (16 waves per row hide the latency that 4 waves x 16 vectors could not: 5.0 -> 5.9 TB/s);
+  // up to 1024*V*16: 1024 threads x 16 vectors, half of them parked in LDS
   int threads = 256, nv = 1;
-  if (P > (int64_t)256 * V * 16) { threads = 1024; nv = 16; }
-  if (P > (int64_t)threads * V * 16) { set_error("score_deflate: row does not fit one workgroup; use score + deflate"); return CMTFPLS_EUNSUPPORTED; }
-  while ((int64_t)threads * V * nv < P) nv *= 4;   // 1, 4, 16
+  if (P > (int64_t)256 * V * 4) { threads = 1024; nv = 4; }
+  if (P > (int64_t)1024 * V * 16) { set_error("score_deflate: row does not fit one workgroup; use score + deflate"); return CMTFPLS_EUNSUPPORTED; }
+  while ((int64_t)threads * V * nv < P) nv *= 4;   // 256 threads: 1, 4; 1024 threads: 4, 16
   const bool kc = v && ((threads * V) % B == 0);
   const bool full = kc && ((int64_t)threads * V * nv == P);
   if (m && full) launch_sd<T, true, true, 2>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);

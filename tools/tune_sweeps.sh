@@ -5,8 +5,8 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "cb2048:-DCMTFPLS_CONTRACT_BLOCKS=2048" "cb512:-DCMTFPLS_CONTRACT_BLOCKS=512" "ru4:-DCMTFPLS_ROW_UNROLL=4" "ru16:-DCMTFPLS_ROW_UNROLL=16"
-          "ntoff:-DCMTFPLS_NT_LOAD=0 -DCMTFPLS_NT_STORE=0")
+VARIANTS=("base:" "b256:-DCMTFPLS_SWEEP_BLOCKS=256" "b768:-DCMTFPLS_SWEEP_BLOCKS=768" "b2048:-DCMTFPLS_SWEEP_BLOCKS=2048" "cb2048:-DCMTFPLS_CONTRACT_BLOCKS=2048" "ru4:-DCMTFPLS_ROW_UNROLL=4"
+          "nopad:-DCMTFPLS_DEFLATE_ROWS_PAD=0" "norows:-DCMTFPLS_DEFLATE_ROWS=0" "ntoff:-DCMTFPLS_NT_LOAD=0 -DCMTFPLS_NT_STORE=0")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
