@@ -15,7 +15,10 @@ namespace cmtfpls {
 // ------------------------------------------------------------------------------------------
 // mode-0 contraction / column statistics
 // ------------------------------------------------------------------------------------------
-constexpr int kContractU = 2;  // 16-byte column groups per thread
+#ifndef CMTFPLS_CONTRACT_U
+#define CMTFPLS_CONTRACT_U 2
+#endif
+constexpr int kContractU = CMTFPLS_CONTRACT_U;  // 16-byte column groups per thread
 constexpr int kYqChunk = 2048;  // rows of u = Y q a workgroup keeps in LDS at a time (YQ variants)
 
 struct ContractPlan {

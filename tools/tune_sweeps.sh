@@ -5,8 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "b256:-DCMTFPLS_SWEEP_BLOCKS=256" "b768:-DCMTFPLS_SWEEP_BLOCKS=768" "b2048:-DCMTFPLS_SWEEP_BLOCKS=2048" "cb2048:-DCMTFPLS_CONTRACT_BLOCKS=2048" "ru4:-DCMTFPLS_ROW_UNROLL=4"
-          "nopad:-DCMTFPLS_DEFLATE_ROWS_PAD=0" "norows:-DCMTFPLS_DEFLATE_ROWS=0" "ntoff:-DCMTFPLS_NT_LOAD=0 -DCMTFPLS_NT_STORE=0")
+VARIANTS=("base:" "u4:-DCMTFPLS_CONTRACT_U=4" "u4b512:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=512" "u4r2:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_UNROLL=2" "u1:-DCMTFPLS_CONTRACT_U=1" "u1r8:-DCMTFPLS_CONTRACT_U=1 -DCMTFPLS_UNROLL=8" "r8:-DCMTFPLS_UNROLL=8")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
