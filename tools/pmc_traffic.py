@@ -15,8 +15,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"contract_vec_kernel": 1, "score_kernel": 1, "deflate_kernel": 2, "center_kernel": 2,
-           "score_deflate_kernel": 2, "xcov_kernel": 1}
+KERNELS = {"contract_vec_kernel": 1, "score_kernel": 1, "deflate_kernel": 2, "deflate_rows_kernel": 2,
+           "deflate_contract_kernel": 2, "center_kernel": 2, "score_deflate_kernel": 2, "xcov_kernel": 1}
 XBYTES = 65536 * 128 * 128 * 4
 
 
@@ -27,6 +27,10 @@ def one_pass(counter, outdir):
            "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--graphs", "0"]
     with open(os.path.join(outdir, "run.log"), "w") as log:
         subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT)
+    return parse(counter, outdir)
+
+
+def parse(counter, outdir):
     files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
     acc = {}
     for row in csv.DictReader(open(files[0])):
@@ -34,17 +38,21 @@ def one_pass(counter, outdir):
             continue
         for key in KERNELS:
             name = row["Kernel_Name"]
-            # X is f32: the f64 instantiations are the same kernels applied to Y or to S (small), not X sweeps
             if f"cmtfpls::{key}<float" in name and not (key == "contract_vec_kernel" and "<float, 2" in name):
                 acc.setdefault(key, []).append(float(row["Counter_Value"]) * 1024.0)
     return acc
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "pmc_traffic.json")
     scratch = os.path.join(ROOT, "gpurun_out", "pmc")
-    fetch = one_pass("FETCH_SIZE", os.path.join(scratch, "fetch"))
-    write = one_pass("WRITE_SIZE", os.path.join(scratch, "write"))
+    if len(sys.argv) > 1 and sys.argv[1] == "--parse":          # re-parse CSVs collected earlier (no GPU needed)
+        out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        fetch = parse("FETCH_SIZE", os.path.join(scratch, "fetch"))
+        write = parse("WRITE_SIZE", os.path.join(scratch, "write"))
+    else:
+        out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        fetch = one_pass("FETCH_SIZE", os.path.join(scratch, "fetch"))
+        write = one_pass("WRITE_SIZE", os.path.join(scratch, "write"))
     kernels = {}
     for key, passes in KERNELS.items():
         if key not in fetch or key not in write:
