@@ -950,7 +950,8 @@ static int run_deflate(T* X, int64_t I, int A, int B, const double* t, const dou
 #endif
     // (shadows the outer lds) > half of the CU's 160 KB of LDS: ONE workgroup (one row) per CU at a time --
     // with two, the read/write streams of the rows interleave at the HBM and the sweep is 4 % slower
-    const size_t lds = loadings_lds_bytes(A, B) + CMTFPLS_DEFLATE_ROWS_PAD;
+    const size_t lds_w = loadings_lds_bytes(A, B);
+    const size_t lds = lds_w + ((lds_w + CMTFPLS_DEFLATE_ROWS_PAD + 1024 <= 160 * 1024) ? CMTFPLS_DEFLATE_ROWS_PAD : 0);
     if (P > (int64_t)256 * V * 4 && P <= (int64_t)1024 * V * 4) {
       if (kc) hipLaunchKernelGGL((deflate_rows_kernel<T, 4, 1024, true>), g, dim3(1024), lds, st, X, I, A, B, t, wA, wB, ssq_part);
       else hipLaunchKernelGGL((deflate_rows_kernel<T, 4, 1024, false>), g, dim3(1024), lds, st, X, I, A, B, t, wA, wB, ssq_part);

@@ -575,3 +575,18 @@ def test_deflate_contract_yq_unsupported(be):
     r = be.deflate_contract_yq(X, 7, 9, dev(rng.normal(size=40)), dev(rng.normal(size=7)), dev(rng.normal(size=9)),
                                dev(rng.normal(size=(40, 3))), dev(rng.normal(size=3)), False, out=be.empty(63))
     assert r is None
+
+
+@pytest.mark.parametrize("shape", [(8, 1, 12000), (6, 4000, 4), (5, 96, 680)])
+def test_deflate_rows_with_large_loadings(be, shape):
+    """Workgroup-per-row deflation where the staged loadings take most of the LDS (the one-row-per-CU
+    padding must then be dropped, not overflow the 160 KB)."""
+    I, A, B = shape
+    x = make_x(shape, "f32", seed=101)
+    rng = np.random.default_rng(102)
+    wa, wb, t = rng.normal(size=A), rng.normal(size=B), rng.normal(size=I)
+    X = dev(x, torch.float32)
+    ssq = be.deflate(X, A, B, dev(t), dev(wa), dev(wb))
+    want = (x - np.outer(t, np.kron(wa, wb))).astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(host(X).astype(np.float64), want, rtol=3e-7, atol=1e-6)
+    np.testing.assert_allclose(host(ssq)[0], np.sum(host(X).astype(np.float64) ** 2), rtol=1e-11)
