@@ -1004,6 +1004,10 @@ static int run_score_deflate(T* X, int64_t I, int A, int B, const double* wA, co
   if (P > (int64_t)256 * V * 4) { threads = 1024; nv = 4; }
   if (P > (int64_t)1024 * V * 16) { set_error("score_deflate: row does not fit one workgroup; use score + deflate"); return CMTFPLS_EUNSUPPORTED; }
   while ((int64_t)threads * V * nv < P) nv *= 4;   // 256 threads: 1, 4; 1024 threads: 4, 16
+  if (threads == 1024 && nv == 16 && lds + (size_t)1024 * 8 * 16 + 1024 > (size_t)160 * 1024) {
+    set_error("score_deflate: loadings + the parked half row exceed the LDS; use score + deflate");
+    return CMTFPLS_EUNSUPPORTED;
+  }
   const bool kc = v && ((threads * V) % B == 0);
   const bool full = kc && ((int64_t)threads * V * nv == P);
   if (m && full) launch_sd<T, true, true, 2>(nv, threads, lds, st, X, I, A, B, wA, wB, rowcnt, t, ssq_part);

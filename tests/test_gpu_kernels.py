@@ -590,3 +590,12 @@ def test_deflate_rows_with_large_loadings(be, shape):
     want = (x - np.outer(t, np.kron(wa, wb))).astype(np.float32).astype(np.float64)
     np.testing.assert_allclose(host(X).astype(np.float64), want, rtol=3e-7, atol=1e-6)
     np.testing.assert_allclose(host(ssq)[0], np.sum(host(X).astype(np.float64) ** 2), rtol=1e-11)
+
+
+def test_score_deflate_unsupported_when_lds_cannot_hold_loadings_and_parked_row(be):
+    """Rows of > 16 K elements park half of the row in LDS (128 KB); with 40 KB of loadings on top the
+    fused kernel must decline (the caller then runs score + deflate), not fail at launch."""
+    rng = np.random.default_rng(103)
+    I, A, B = 3, 4, 5000                                        # P = 20000, loadings 40 KB
+    X = dev(rng.normal(size=(I, A * B)), torch.float32)
+    assert be.score_deflate(X, A, B, dev(rng.normal(size=A)), dev(rng.normal(size=B)), None, be.empty(I)) is None
