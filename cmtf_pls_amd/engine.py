@@ -318,10 +318,10 @@ class FitRun:
         self.use_graphs = False
         self._graphs = {}
         self._graph_error = None
-        # Fused Y side (one block, M <= 64): u = Y q is formed inside the contraction and Y^T t inside the
-        # score kernel, so an iteration has no launch of its own for either; q lives in two buffers that
+        # Fused Y side (M <= 64): u = Y q is formed inside the contraction and Y^T t inside the score
+        # kernel, so an iteration has no launch of its own for either; q lives in two buffers that
         # alternate by parity (a captured graph holds their addresses) and |du|^2 is the quadratic form
-        # dq^T (Y^T Y) dq.  Other shapes keep the separate gram_tn / normalize / rowdot launches.
+        # dq^T (Y^T Y) dq.  More responses keep the separate gram_tn / normalize / rowdot launches.
         # Coupled blocks: normalize(Y^T mean_b t_b) = normalize(sum_b Y^T t_b), so every block's score kernel
         # adds its partial rows and the averaged score itself is only formed once per component.
         self._pending = None                      # (component, [ssq per block..., ssq of Y]) still on the device
