@@ -139,6 +139,17 @@ class HipBackend:
         _lib.check(fn(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
         return S
 
+    def xcov_iterate(self, S: torch.Tensor, A: int, B: int, q_cur: torch.Tensor, Z: torch.Tensor, wA: torch.Tensor,
+                     wB: torch.Tensor, info: torch.Tensor, n_squarings: int, q_new: torch.Tensor, G: torch.Tensor,
+                     du2: torch.Tensor, first: bool) -> None:
+        """One inner iteration on S (contraction, rank-1, score, norm, |du|^2) issued by one host call."""
+        M, P = S.shape
+        wc = self._workspace("contract", self.lib.cmtfpls_mode0_contract_workspace_bytes(M, P))
+        wr = self._workspace("rank1", self.lib.cmtfpls_rank1_workspace_bytes(A, B))
+        _lib.check(self.lib.cmtfpls_xcov_iterate_f64(_ptr(S), M, A, B, _ptr(q_cur), _ptr(Z), _ptr(wA), _ptr(wB), _ptr(info),
+                                                     int(n_squarings), _ptr(q_new), _ptr(G), _ptr(du2), int(first),
+                                                     _ptr(wc), wc.numel(), _ptr(wr), wr.numel(), self._stream()), "xcov_iterate")
+
     def s_downdate(self, S: torch.Tensor, A: int, B: int, ya: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
                    q: torch.Tensor, v: torch.Tensor) -> None:
         """S -= ya w^T + q v^T, w = kron(wA, wB): S = Y^T X_(0) carried across one deflation."""

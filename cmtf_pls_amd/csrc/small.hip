@@ -340,6 +340,25 @@ int cmtfpls_s_downdate_f64(double* S, int M, int A, int B, const double* ya, con
   return check_launch("s_downdate");
 }
 
+// One inner iteration of the cross-covariance form issued by ONE host call (its kernels are tiny: a
+// Python-side launch per kernel leaves the GPU idle between them).  Calls the entries above in order.
+int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double* q_cur, double* Z, double* wA, double* wB,
+                             double* info, int n_squarings, double* q_new, const double* G, double* du2, int first,
+                             void* ws_contract, size_t ws_contract_bytes, void* ws_rank1, size_t ws_rank1_bytes, void* stream) {
+  if (!S || !q_cur || !Z || !wA || !wB || !q_new || !G || !du2 || M <= 0 || A <= 0 || B <= 0) {
+    set_error("xcov_iterate: bad argument");
+    return CMTFPLS_EINVAL;
+  }
+  if (M > 64) { set_error("xcov_iterate: more than 64 responses"); return CMTFPLS_EUNSUPPORTED; }
+  const int64_t P = (int64_t)A * B;
+  int rc = CMTFPLS_OK;
+  if (first) rc = cmtfpls_mode0_contract_f64(S, M, P, q_cur, Z, 0, ws_contract, ws_contract_bytes, stream);   // Z = sum_m q_m S_m
+  if (rc == CMTFPLS_OK) rc = cmtfpls_rank1_f64(Z, A, B, wA, wB, nullptr, info, n_squarings, ws_rank1, ws_rank1_bytes, stream);
+  if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(S, M, A, B, wA, wB, nullptr, q_new, stream);                   // Y^T t = S (wA (x) wB)
+  if (rc == CMTFPLS_OK) rc = cmtfpls_q_update_f64(nullptr, 0, M, q_new, 1, G, q_cur, du2, stream);            // / norm, |du|^2
+  return rc;
+}
+
 int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_samples, void* stream) {
   if (!Z || !colcnt || P <= 0) { set_error("colscale: bad argument"); return CMTFPLS_EINVAL; }
   hipLaunchKernelGGL(colscale_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, P, colcnt, n_samples);

@@ -344,7 +344,8 @@ class FitRun:
             self.Yw = be.empty(I, M) if any(blk.has_miss for blk in self.blocks) else None
             self.Gy = be.empty(M, M)
             self.Tq = be.empty(nb, M)
-            self.qc = be.empty(M)
+            self.qx = [be.zeros(M), be.zeros(M)]      # q of the current / next iteration, alternating by parity
+            self.qc = self.qx[0]
             self.qn = self.Tq[0] if (nb == 1 and not coupled) else be.empty(M)
             # S is carried across a deflation instead of rebuilt when no block has missing values:
             # S+ = S - (Y^T t) w^T - q (X+^T yhat)^T, with X+^T yhat formed inside the deflation sweep
@@ -382,6 +383,8 @@ class FitRun:
         self._s_ready = False
         be.gram_tn(self.Y, self.Y, out=self.Gy)
         comm.allreduce(self.Gy)
+        self._parity = 0
+        self.qc = self.qx[0]
         self.qc.zero_()
         self.qc[0] = 1.0                                          # u_0 = Y[:, 0] = Y e_0   (tpls.py:78)
 
@@ -391,7 +394,20 @@ class FitRun:
         be = self.eng.be
         self._executed += 1
 
+        blk0 = self.blocks[0]
+        composite = (len(self.blocks) == 1 and len(blk0.shape) == 3 and not blk0.has_miss and self.M <= 64
+                     and self.qn.data_ptr() == self.Tq.data_ptr() and hasattr(be, "xcov_iterate"))
+
+        par = self._parity
+        q_cur, q_new = self.qx[par], self.qx[par ^ 1]
+
         def seg(first: bool):
+            if composite:
+                # the whole iteration (its kernels are tiny) is issued by one host call; q alternates between
+                # two buffers (no copy, and a captured graph keeps their addresses)
+                be.xcov_iterate(self.S[0], blk0.A, blk0.B, q_cur, self.Zs[0], self.wA[0], self.wB[0], self.status[1:3],
+                                self.sq_budget[0], q_new, self.Gy, self.status[0:1], first)
+                return
             if first:
                 for b, blk in enumerate(self.blocks):
                     be.mode0_contract(self.S[b], self.qc, False, out=self.Zs[b])     # tpls.py:80-83
@@ -409,12 +425,16 @@ class FitRun:
 
         first = True
         while True:
-            self._run(("xcov", it > 0, tuple(self.sq_budget), first), lambda: seg(first))
+            self._run(("xcov", it > 0, tuple(self.sq_budget), first, par if composite else -1), lambda: seg(first))
             host = self._read_status()
             if not self._update_budgets(host):
                 break
             first = False
-        self.qc.copy_(self.qn)                   # fixed buffers (a captured graph holds their addresses)
+        if composite:
+            self._parity ^= 1
+            self.qc = q_new
+        else:
+            self.qc.copy_(self.qn)               # fixed buffers (a captured graph holds their addresses)
         return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))
 
     def _update_budgets(self, host) -> bool:
@@ -426,9 +446,10 @@ class FitRun:
                 self.sq_budget[b] = self.sq_max
                 retry = True
             elif conv and len(self.blocks[b].shape) == 3:
-                # hysteresis keeps the launch sequence (and a captured graph of it) stable
-                # convergence is seen by launch used + 1; keep one spare, re-plan only outside [used+1, used+4]
-                if used + 1 > self.sq_budget[b] or used + 4 < self.sq_budget[b]:
+                # convergence is seen by launch used + 1; keep one spare.  Under graph replay the launch sequence
+                # is part of the captured graph: hysteresis (re-plan only outside [used+1, used+4]) keeps it stable;
+                # eager launches follow the need exactly (every spare launch is 4.5 us of an idle GPU)
+                if not self.use_graphs or used + 1 > self.sq_budget[b] or used + 4 < self.sq_budget[b]:
                     self.sq_budget[b] = min(self.sq_max, used + 2)
         return retry
 

@@ -115,6 +115,14 @@ int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int 
 int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
                      int masked, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream);
+/* One inner iteration of the loop on S (tpls.py:80-103 re-associated) issued by a single host call:
+ * Z = sum_m q_cur[m] S[m,:] (only if first != 0), rank1(Z) -> (wA, wB, info), q_new = S (wA (x) wB) normalised,
+ * du2 = (q_new - q_cur)^T G (q_new - q_cur).  Same kernels as the separate entries; workspaces as
+ * cmtfpls_mode0_contract_workspace_bytes(M, A*B) and cmtfpls_rank1_workspace_bytes(A, B).  M <= 64. */
+int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double* q_cur, double* Z, double* wA,
+                             double* wB, double* info, int n_squarings, double* q_new, const double* G, double* du2,
+                             int first, void* ws_contract, size_t ws_contract_bytes, void* ws_rank1,
+                             size_t ws_rank1_bytes, void* stream);
 /* S carried across one deflation instead of rebuilt (tpls.py:109 and :113 applied to S = Y^T X_(0)):
  * with X+ = X - t w^T and Y+ = Y - yhat q^T (yhat = T b, the inner-regression prediction),
  *   S+ = S - ya w^T - q v^T,   ya = Y^T t (M, taken before Y is deflated),  v = X+^T yhat (P, from

@@ -90,6 +90,13 @@ class NumpyBackend:
             return out
         return S
 
+    def xcov_iterate(self, S, A, B, q_cur, Z, wA, wB, info, n_squarings, q_new, G, du2, first):
+        if first:
+            self.mode0_contract(S, q_cur, False, out=Z)
+        self.rank1(Z, A, B, wA, wB, info=info, n_squarings=n_squarings)
+        self.score(S, A, B, wA, wB, None, q_new)
+        self.q_update(q_new, None, True, G, q_cur, du2)
+
     def s_downdate(self, S, A, B, ya, wA, wB, q, v):
         S -= torch.outer(ya.reshape(-1), torch.from_numpy(self._w(wA, wB))) + torch.outer(q, v)
 
