@@ -67,8 +67,10 @@ def main():
             rec["ms_per_iter_graphs" if graphs else "ms_per_iter_eager"] = ms
             rec["x_TBps_graphs" if graphs else "x_TBps_eager"] = 2 * xbytes / ms / 1e9
         for algo in ("direct", "xcov"):
-            s, n = time_fit(eng, Xs, Y, R, coupled, algo)
-            rec[f"fit_{algo}_s"] = s
+            s0, n = time_fit(eng, Xs, Y, R, coupled, algo)     # first call: includes one-time allocations / module loads
+            s1, n = time_fit(eng, Xs, Y, R, coupled, algo)
+            rec[f"fit_{algo}_s"] = s1
+            rec[f"fit_{algo}_first_call_s"] = s0
             rec[f"fit_{algo}_iters"] = sum(n)
         print(json.dumps(rec), flush=True)
         del Xs, Y, out
