@@ -20,6 +20,9 @@ namespace cmtfpls {
 #endif
 constexpr int kContractU = CMTFPLS_CONTRACT_U;  // 16-byte column groups per thread
 constexpr int kYqChunk = 2048;  // rows of u = Y q a workgroup keeps in LDS at a time (YQ variants)
+#ifndef CMTFPLS_YQ_ROWS_IN_FLIGHT
+#define CMTFPLS_YQ_ROWS_IN_FLIGHT 4    // 8 is within noise; 16 costs 40 VGPRs (occupancy 3) and a third of the bandwidth
+#endif
 
 struct ContractPlan {
   int vec;            // 1: vector kernel, 0: scalar kernel
@@ -58,7 +61,7 @@ __device__ __forceinline__ void rows_times_q_impl(const double* __restrict__ Y, 
   const int nrows = (int)(r1 - r0);
   const int trips = (nrows + ngrp - 1) / ngrp;
   const double* __restrict__ Yb = Y + r0 * ldy + msafe;
-  constexpr int K = 4;                                  // rows in flight per lane group
+  constexpr int K = CMTFPLS_YQ_ROWS_IN_FLIGHT;           // rows in flight per lane group
   for (int tr = 0; tr < trips; tr += K) {
     double v[K];
 #pragma unroll

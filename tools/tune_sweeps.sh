@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "u4:-DCMTFPLS_CONTRACT_U=4" "u4b512:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=512" "u4r2:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_UNROLL=2" "u1:-DCMTFPLS_CONTRACT_U=1" "u1r8:-DCMTFPLS_CONTRACT_U=1 -DCMTFPLS_UNROLL=8" "r8:-DCMTFPLS_UNROLL=8")
+VARIANTS=("base:" "k4:-DCMTFPLS_YQ_ROWS_IN_FLIGHT=4" "k8:-DCMTFPLS_YQ_ROWS_IN_FLIGHT=8" "cb1280:-DCMTFPLS_CONTRACT_BLOCKS=1280" "cb1280k4:-DCMTFPLS_CONTRACT_BLOCKS=1280 -DCMTFPLS_YQ_ROWS_IN_FLIGHT=4")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
