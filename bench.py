@@ -275,13 +275,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(J, K, M, R, args.noise, args.cpu_rows, I_total)
 
+    cfg_name = {(65536, 128, 128, 16): "BASELINE configs[1]", (262144, 256, 256, 32): "BASELINE configs[4]"}.get(
+        (I_total, J, K, M), "custom shape")
     if rank == 0:
         out = {
             "metric": "nipals_iters_per_sec", "value": args.steps / elapsed, "unit": "it/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: tPLS direct NIPALS iteration, X {I_total}x{J}x{K} f32 "
+            "config": {"workload": f"{cfg_name}: tPLS direct NIPALS iteration, X {I_total}x{J}x{K} f32 "
                                    f"(f64 accumulation), Y {I_total}x{M}, R={R}, noise {args.noise}",
                        "rows_per_gpu": rows, "parallelism": f"sample-mode shard x{world}" if world > 1 else "single GPU",
                        "x_reads_per_step": 2, "hip_graphs": bool(graphs_used), "graph_error": graph_error,
