@@ -20,9 +20,6 @@ namespace cmtfpls {
 #endif
 constexpr int kContractU = CMTFPLS_CONTRACT_U;  // 16-byte column groups per thread
 constexpr int kYqChunk = 2048;  // rows of u = Y q a workgroup keeps in LDS at a time (YQ variants)
-#ifndef CMTFPLS_YQ_ROWS_IN_FLIGHT
-#define CMTFPLS_YQ_ROWS_IN_FLIGHT 4    // 8 is within noise; 16 costs 40 VGPRs (occupancy 3) and a third of the bandwidth
-#endif
 
 struct ContractPlan {
   int vec;            // 1: vector kernel, 0: scalar kernel
@@ -49,41 +46,27 @@ static ContractPlan plan_contract(int64_t I, int64_t P, int elem) {
 
 // u[i] = sum_m Y[i, m] q[m] for the rows [r0, r1) of one workgroup, into LDS (YQ variants: the Y
 // update u = Y q of tpls.py:102 is formed where it is consumed instead of by a launch of its own).
-// L = 16 / 32 / 64 lanes share a row (coalesced read of the Y row), summed by a butterfly.
-template <int L>
-__device__ __forceinline__ void rows_times_q_impl(const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q,
-                                                  int64_t r0, int64_t r1, double* __restrict__ us) {
-  constexpr int ngrp = kSweepThreads / L;
-  const int sub = threadIdx.x & (L - 1), grp = threadIdx.x / L;
-  const double qm = (sub < M) ? q[sub] : 0.0;
-  const int msafe = (sub < M) ? sub : 0;
-  // every group runs the same number of trips (the shuffles need all lanes): rows past r1 are clamped
-  const int nrows = (int)(r1 - r0);
-  const int trips = (nrows + ngrp - 1) / ngrp;
-  const double* __restrict__ Yb = Y + r0 * ldy + msafe;
-  constexpr int K = CMTFPLS_YQ_ROWS_IN_FLIGHT;           // rows in flight per lane group
-  for (int tr = 0; tr < trips; tr += K) {
-    double v[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int rr = (tr + k) * ngrp + grp;
-      v[k] = Yb[(int64_t)((rr < nrows) ? rr : nrows - 1) * ldy] * qm;
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int rr = (tr + k) * ngrp + grp;
-#pragma unroll
-      for (int off = L >> 1; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-      if (sub == 0 && rr < nrows) us[rr] = v[k];
-    }
-  }
-  __syncthreads();
-}
+// One thread per row, m ascending (the order of cmtfpls_rowdot_f64, bit for bit), 8 loads in flight.
+// (A lane-group-per-row version with butterfly sums needed 40 more VGPRs for its shuffle indices and set
+// the register count -- hence the occupancy -- of the whole contraction kernel.)
 __device__ __forceinline__ void rows_times_q(const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q,
                                              int64_t r0, int64_t r1, double* __restrict__ us) {
-  if (M <= 16) rows_times_q_impl<16>(Y, ldy, M, q, r0, r1, us);
-  else if (M <= 32) rows_times_q_impl<32>(Y, ldy, M, q, r0, r1, us);
-  else rows_times_q_impl<64>(Y, ldy, M, q, r0, r1, us);
+  const int nrows = (int)(r1 - r0);
+  for (int rr = threadIdx.x; rr < nrows; rr += kSweepThreads) {
+    const double* __restrict__ yr = Y + (r0 + rr) * ldy;
+    double s = 0.0;
+    int m = 0;
+    for (; m + 8 <= M; m += 8) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = yr[m + k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = fma(v[k], q[m + k], s);
+    }
+    for (; m < M; ++m) s = fma(yr[m], q[m], s);
+    us[rr] = s;
+  }
+  __syncthreads();
 }
 
 // MODE 0: plain (NaN propagates, as np.einsum)  1: NaN -> 0  2: statistics (u == 1, NaN -> 0, count)
