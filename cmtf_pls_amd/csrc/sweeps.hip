@@ -20,6 +20,10 @@ namespace cmtfpls {
 #endif
 constexpr int kContractU = CMTFPLS_CONTRACT_U;  // 16-byte column groups per thread
 constexpr int kYqChunk = 2048;  // rows of u = Y q a workgroup keeps in LDS at a time (YQ variants)
+#ifndef CMTFPLS_YQ_UNFUSE_TILES
+#define CMTFPLS_YQ_UNFUSE_TILES 16
+#endif
+constexpr int kYqUnfuseTiles = CMTFPLS_YQ_UNFUSE_TILES;   // column tiles from which u = Y q is formed once, up front
 
 struct ContractPlan {
   int vec;            // 1: vector kernel, 0: scalar kernel
@@ -429,7 +433,11 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   }
   if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) { set_error("X must be 16-byte aligned"); return CMTFPLS_EINVAL; }
   const ContractPlan p = plan_contract(I, P, (int)sizeof(T));
-  const size_t need = (size_t)p.row_blocks * (size_t)P * sizeof(double) * (MODE == 2 ? 2 : 1);
+  // Wide blocks (>= kYqUnfuseTiles column tiles): every column tile of a row block would repeat the same
+  // u = Y q prologue, so u is formed once by the rowdot kernel into the tail of the workspace instead
+  // (262144 x 256 x 256, M = 32: 2 % of the sweep)
+  const bool yq_pre = yq && p.vec && M <= 64 && MODE != 2 && p.col_tiles >= kYqUnfuseTiles;
+  const size_t need = (size_t)p.row_blocks * (size_t)P * sizeof(double) * (MODE == 2 ? 2 : 1) + (yq_pre ? (size_t)I * sizeof(double) : 0);
   if (!ws || ws_bytes < need) { set_error("mode0_contract/colstats: workspace too small"); return CMTFPLS_EWORKSPACE; }
   double* part = static_cast<double*>(ws);
   double* cntpart = (MODE == 2) ? part + (size_t)p.row_blocks * P : nullptr;
@@ -438,7 +446,13 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   const int ncv = p.vec ? (int)(P / Vt) : 0;
   const bool narrow = p.vec && ncv <= kSweepThreads / 2;          // at least two rows per workgroup pass
   const int RS = narrow ? kSweepThreads / ncv : 1;
-  if (yq) {
+  if (yq_pre) {
+    double* u_ws = part + (size_t)p.row_blocks * P;
+    const int rc = cmtfpls_rowdot_f64(Y, ldy, M, I, q, u_ws, nullptr, nullptr, nullptr, 0, st);
+    if (rc != CMTFPLS_OK) return rc;
+    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u_ws, part, cntpart,
+                       p.rows_per_block, nullptr, 0, 0, nullptr);
+  } else if (yq) {
     // supported: vector shape, M <= 64 (one Y row per wavefront pass)
     const size_t lds = (size_t)kYqChunk * sizeof(double);
     if (!p.vec || M > 64 || MODE == 2) {
@@ -1020,7 +1034,7 @@ size_t cmtfpls_mode0_contract_workspace_bytes(int64_t I, int64_t P) {
   // the f64 plan never has fewer row blocks than the f32 plan for the same shape: size for both
   const ContractPlan a = plan_contract(I, P, 4), b = plan_contract(I, P, 8);
   const int rb = a.row_blocks > b.row_blocks ? a.row_blocks : b.row_blocks;
-  return (size_t)rb * (size_t)P * sizeof(double);
+  return (size_t)rb * (size_t)P * sizeof(double) + (size_t)I * sizeof(double);   // + u = Y q of the wide-block form
 }
 size_t cmtfpls_colstats_workspace_bytes(int64_t I, int64_t P) { return 2 * cmtfpls_mode0_contract_workspace_bytes(I, P); }
 

@@ -516,11 +516,12 @@ def test_score_gram_more_than_64_responses_is_unsupported(be):
     assert be.score_gram(X, 4, 8, dev(rng.normal(size=4)), dev(rng.normal(size=8)), None, be.empty(20), Y, be.empty(be.n_partials * 65)) is None
 
 
-@pytest.mark.parametrize("I,A,B", [(70000, 256, 256), (2_200_000, 2, 4)])
+@pytest.mark.parametrize("I,A,B", [(270000, 128, 128), (70000, 256, 256), (2_200_000, 2, 4)])
 def test_mode0_contract_yq_row_chunks(be, I, A, B):
     """Workgroups whose row range exceeds one LDS chunk of u = Y q (2048 rows): the wide kernel at
-    70000 x 65536 (2188 rows per workgroup) and the narrow kernel at 2.2M x 8.  Data and the f64
-    reference are formed on the device (the tensors are 18 GB / 70 MB)."""
+    270000 x 16384 (2110 rows per workgroup) and the narrow kernel at 2.2M x 8; and 70000 x 65536, where
+    the 32 column tiles make the entry form u once up front instead.  Data and the f64 reference are
+    formed on the device (the tensors are 18 GB / 18 GB / 70 MB)."""
     P, M = A * B, 16
     g = torch.Generator(device="cuda:0").manual_seed(123)
     X = torch.randn(I, P, device="cuda:0", dtype=torch.float32, generator=g)
