@@ -495,13 +495,24 @@ static int run_deflate_contract(T* X, int64_t I, int A, int B, const double* t, 
     return CMTFPLS_EUNSUPPORTED;
   }
   const size_t nss = (size_t)p.col_tiles * p.row_blocks;
-  const size_t need = ((size_t)p.row_blocks * (size_t)P + nss) * sizeof(double);
+  const bool pre = p.col_tiles >= kYqUnfuseTiles;          // wide block: u = Y q once, up front (see run_contract)
+  const size_t need = ((size_t)p.row_blocks * (size_t)P + nss + (pre ? (size_t)I : 0)) * sizeof(double);
   if (!ws || ws_bytes < need) { set_error("deflate_contract_yq: workspace too small"); return CMTFPLS_EWORKSPACE; }
   double* part = static_cast<double*>(ws);
   double* sspart = part + (size_t)p.row_blocks * P;
   const dim3 grid(p.col_tiles, p.row_blocks);
   const size_t lds = (size_t)kYqChunk * sizeof(double);
-  if (masked)
+  if (pre) {
+    double* u_ws = sspart + nss;
+    const int rc = cmtfpls_rowdot_f64(Y, ldy, M, I, q, u_ws, nullptr, nullptr, nullptr, 0, st);
+    if (rc != CMTFPLS_OK) return rc;
+    if (masked)
+      hipLaunchKernelGGL((deflate_contract_kernel<T, 1, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, B, t, wA, wB, u_ws,
+                         part, sspart, p.rows_per_block, nullptr, 0, 0, nullptr);
+    else
+      hipLaunchKernelGGL((deflate_contract_kernel<T, 0, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, B, t, wA, wB, u_ws,
+                         part, sspart, p.rows_per_block, nullptr, 0, 0, nullptr);
+  } else if (masked)
     hipLaunchKernelGGL((deflate_contract_kernel<T, 1, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, B, t, wA, wB, nullptr,
                        part, sspart, p.rows_per_block, Y, ldy, M, q);
   else
@@ -1066,7 +1077,7 @@ size_t cmtfpls_deflate_contract_workspace_bytes(int64_t I, int64_t P) {
   if (I <= 0 || P <= 0) return 0;
   const ContractPlan a = plan_contract(I, P, 4), b = plan_contract(I, P, 8);
   const size_t na = (size_t)a.row_blocks * ((size_t)P + a.col_tiles), nb = (size_t)b.row_blocks * ((size_t)P + b.col_tiles);
-  return (na > nb ? na : nb) * sizeof(double);
+  return ((na > nb ? na : nb) + (size_t)I) * sizeof(double);   // + u = Y q of the wide-block form
 }
 int cmtfpls_deflate_contract_yq_f32(float* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB,
                                     const double* Y, int ldy, int M, const double* q, double* Z, int masked, double* ssq,

@@ -544,7 +544,7 @@ def test_mode0_contract_yq_row_chunks(be, I, A, B):
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 @pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("shape,M", [((37, 10, 8), 4), ((300, 16, 16), 16), ((1000, 16, 64), 17), ((50, 128, 128), 33),
-                                     ((2500, 2, 4), 3)])
+                                     ((2500, 2, 4), 3), ((40, 256, 128), 5)])        # the last: 16 column tiles (u formed up front)
 def test_deflate_contract_yq(be, shape, M, dt, masked):
     """tpls.py:109 fused with tpls.py:80-83 of the next component: bit-identical to deflate followed by
     mode0_contract_yq on the deflated X; the sum of squares equals the deflate kernel's to rounding."""
