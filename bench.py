@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- NIPALS iterations/sec (+ sec-to-fit R=10) of the MI355X tPLS engine.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torch.distributed.run,
-one rank per GPU over RCCL).  A *step* is ONE direct-form NIPALS inner iteration of the product
-engine (cmtf_pls_amd.engine.FitRun.iterate = reference tpls.py:80-107): mode-0 contraction (one
-read of X), rank-1 extraction, score contraction (second read of X), Y update, convergence norm
-read back to the host exactly as the reference tests it every iteration.  Inputs are resident in
-HBM before the timed region.  Workload: BASELINE.json configs[1] (X 65536x128x128 f32, Y 65536x16,
-R=10), STRONG scaling: the same X is row-sharded over the N ranks, as the metric is quoted
-("iters/sec on X 65536x128x128 at 1/2/4/8 GPU").
+Contract: ``python bench.py --gpus N --steps K --warmup W``.  With N > 1 and no WORLD_SIZE in the
+environment this process touches no GPU: it starts ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`` as a child (one rank per GPU over
+RCCL), forwards its output and exits with its code.  Launched BY torch.distributed.run (WORLD_SIZE set),
+it is one rank; WORLD_SIZE != --gpus is refused with a non-zero exit before any GPU call, and the process
+group is checked to have exactly N ranks.
 
-Rank 0 prints ONE JSON line; ``roofline`` is the dominant kernel (the mode-0 contraction launch)
-from HIP events on the launch stream inside the timed region; ``cpu_baseline`` is the NumPy oracle's
-inner loop timed on this host on a row sample (rank 0, N=1 only).
+A *step* is ONE direct-form NIPALS inner iteration of the product engine
+(cmtf_pls_amd.engine.FitRun.iterate = reference tpls.py:80-107): mode-0 contraction (one read of X),
+rank-1 extraction, score contraction (second read of X), Y update, convergence norm read back to the
+host exactly as the reference tests it every iteration.  Inputs are resident in HBM before the timed
+region.  Workload: BASELINE.json configs[1] (X 65536x128x128 f32, Y 65536x16, R=10), STRONG scaling:
+the same X is row-sharded over the N ranks, as the metric is quoted ("iters/sec on X 65536x128x128 at
+1/2/4/8 GPU"); per iteration the ranks all-reduce Z (J*K doubles) and Y^T t (M doubles).
+
+Rank 0 prints ONE JSON line; ``roofline`` is the dominant kernel (the mode-0 contraction launch) from HIP
+events on the launch stream inside the timed region, against the 8 TB/s spec peak AND against streaming
+ceilings measured in the same run (``peak_measured_read`` / ``peak_measured_rmw``: plain float4
+read-only / read-modify-write kernels of libcmtfpls over an X-sized buffer); ``cpu_baseline`` is the
+NumPy oracle's inner loop timed on this host on a row sample (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,9 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+F64_MFMA_PEAK_TF = 78.6  # MI355X dense f64 matrix peak (v_mfma_f64_16x16x4_f64)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -40,9 +51,35 @@ def parse():
     ap.add_argument("--noise", type=float, default=0.1)
     ap.add_argument("--no-fit", action="store_true", help="skip the sec-to-fit leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the measured streaming ceilings")
     ap.add_argument("--cpu-rows", type=int, default=2048)
     ap.add_argument("--graphs", type=int, default=1, help="replay the iteration's launch sequence as a HIP graph (0 = eager)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---- launcher (no GPU call may happen before or inside these two functions) -----------------------
+def launcher_command(n_gpus, argv, port=None):
+    """The child command that runs this file as n_gpus ranks (one per GPU) of one node."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def resolve_world(args, environ):
+    """('launch', N) when this process must start its own ranks, ('rank', world) when it is one rank.
+    A WORLD_SIZE that disagrees with --gpus is refused (SystemExit, non-zero) -- a scaling run must never
+    record N=1 work under n_gpus=N."""
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus must be >= 1, got {args.gpus}")
+    ws = environ.get("WORLD_SIZE")
+    if ws is None:
+        return ("launch", args.gpus) if args.gpus > 1 else ("rank", 1)
+    if int(ws) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: refusing to run a mislabelled job")
+    return ("rank", int(ws))
 
 
 def synth_shard(I_total, J, K, M, L, noise, row0, rows, device, seed=215):
@@ -76,6 +113,20 @@ class EventTimer:
         ev = self.records[name]
         return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
+    def time_calls(self, fn, n=5, warm=1):
+        """Average duration (ms) of n calls of fn, each bracketed by its own event pair, after `warm` untimed calls."""
+        for _ in range(warm):
+            fn()
+        pairs = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / n
+
 
 def cpu_baseline(J, K, M, L, noise, rows, I_total):
     """The oracle's inner loop (NumPy float64, the reference's arithmetic) on a row sample."""
@@ -103,28 +154,78 @@ def cpu_baseline(J, K, M, L, noise, rows, I_total):
             "host_cpu_count": os.cpu_count()}
 
 
+def measure_ceilings(be, timer, scratch, src, row_bytes):
+    """Streaming ceilings of THIS box, measured with the plain float4 kernels of libcmtfpls (csrc/ceiling.hip)
+    over an X-sized buffer: best of a few (address map, grid) variants per access pattern, all reported."""
+    nbytes = scratch.numel() * scratch.element_size()
+    res = {"buffer_GB": nbytes / 1e9, "variants": {}}
+    best = {}
+    for op, passes in (("read", 1), ("rmw", 2), ("copy", 2)):
+        for rb in (0, row_bytes):
+            for blocks in (1024, 2048, 4096):
+                if op == "copy":
+                    fn = lambda: be.ceiling("copy", src, rb, blocks, dst=scratch)
+                else:
+                    fn = lambda: be.ceiling(op, scratch, rb, blocks)
+                ms = timer.time_calls(fn, n=4, warm=2)          # an even number of rmw launches: data restored
+                gbps = passes * nbytes / ms / 1e6
+                res["variants"][f"{op}:{'rows' if rb else 'flat'}:{blocks}"] = round(gbps, 1)
+                if gbps > best.get(op, 0.0):
+                    best[op] = gbps
+    res["read_GBps"], res["rmw_GBps"], res["copy_GBps"] = best["read"], best["rmw"], best["copy"]
+    return res
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    mode, world = resolve_world(args, os.environ)
+    if mode == "launch":
+        # nothing above touched the GPU: starting the ranks as children is allowed
+        proc = subprocess.run(launcher_command(world, sys.argv[1:]))
+        raise SystemExit(proc.returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # rehearsal hooks (one-GPU box): BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo
-    # replaces RCCL, which refuses two ranks on one device; the driver's runs use neither
+    # replaces RCCL, which refuses two ranks on one device; BENCH_FORCE_DIST=1 makes a single rank create
+    # its RCCL communicator and issue the engine's collectives anyway; the driver's runs use none of them
     dev_index = 0 if os.environ.get("BENCH_ONE_DEVICE") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    backend = None
+    if world > 1 or force_dist:
         backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from cmtf_pls_amd.backend import HipBackend
     from cmtf_pls_amd.engine import Comm, NipalsEngine
+
+    class TimedComm(Comm):
+        """Comm whose all-reduces are bracketed by HIP events on the launch stream while `on` is set (the
+        collective runs on RCCL's stream; the launch stream waits for it, so the pair spans it)."""
+        on = False
+        pairs = []
+
+        def allreduce(self, t):
+            if not (self.on and self.sharded):
+                return super().allreduce(t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = super().allreduce(t)
+            e1.record()
+            self.pairs.append((e0, e1, t.numel() * t.element_size()))
+            return out
 
     I_total, J, K = args.shape
     M, R = args.responses, args.components
@@ -136,7 +237,8 @@ def main():
     # the unfused names stay bracketed for shapes that fall back to them
     timer = EventTimer(be, ["mode0_contract", "mode0_contract_yq", "score", "score_gram", "rank1", "q_update", "gram_tn",
                             "rowdot", "deflate"])
-    eng = NipalsEngine(be, Comm() if world > 1 else None)
+    comm = TimedComm(force=force_dist) if backend else None
+    eng = NipalsEngine(be, comm)
 
     # ---- timed leg: K direct NIPALS iterations of component 0 -------------------------------
     Xw, Yw = X.clone(), Y.clone()
@@ -151,6 +253,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         timer.on = events
+        if comm is not None:
+            comm.on = events
         t0 = time.perf_counter()
         for _ in range(steps):
             run.iterate(state["it"])               # it > 0 after warm-up: convergence norm computed and read back
@@ -161,6 +265,8 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         timer.on = False
+        if comm is not None:
+            comm.on = False
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -201,30 +307,68 @@ def main():
         kern[name] = {"ms": ms, "alg_GB": nbytes / 1e9, "GBps": nbytes / ms / 1e6 if ms else None, "entry": src}
     for name in (("rank1", "q_update") if fused else ("rank1", "gram_tn", "rowdot")):
         kern[name] = {"ms": timer.mean_ms(name)}
-    # deflation sweep (read + write of X), HIP events over 5 launches
-    timer.on = True
+    # the read-modify-write sweeps of the fit path (2 * I * P * s algorithmic bytes each), HIP events over 5 launches
+    blk = run.blocks[0]
     tz = torch.zeros(rows, dtype=torch.float64, device=device)
-    for _ in range(5):
-        be.deflate(run.X2[0], run.blocks[0].A, run.blocks[0].B, tz, run.wA[0], run.wB[0])
-    torch.cuda.synchronize()
-    timer.on = False
-    ms = timer.mean_ms("deflate")
-    kern["deflate"] = {"ms": ms, "alg_GB": 2 * xbytes / 1e9, "GBps": 2 * xbytes / ms / 1e6}
+    zmean = torch.zeros(J * K, dtype=torch.float64, device=device)
+    Zs = torch.empty(J * K, dtype=torch.float64, device=device)
+    q1 = torch.ones(M, dtype=torch.float64, device=device)
+    t_out = torch.empty(rows, dtype=torch.float64, device=device)
+    rmw = {   # t = 0 / mean = 0: X keeps its values, the traffic is the real one
+        "deflate": lambda: be.deflate(run.X2[0], blk.A, blk.B, tz, run.wA[0], run.wB[0]),
+        "deflate_contract_yq": lambda: be.deflate_contract_yq(run.X2[0], blk.A, blk.B, tz, run.wA[0], run.wB[0], run.Y, q1, False, out=Zs),
+        "score_deflate": lambda: be.score_deflate(run.X2[0], blk.A, blk.B, run.wA[0], run.wB[0], None, t_out),
+        "center": lambda: be.center(run.X2[0], zmean, False),
+    }
+    for name, fn in rmw.items():
+        try:
+            ms = timer.time_calls(fn, n=5, warm=1)
+            kern[name] = {"ms": ms, "alg_GB": 2 * xbytes / 1e9, "GBps": 2 * xbytes / ms / 1e6}
+        except Exception as e:                     # a shape outside one fused form must not lose the run
+            kern[name] = {"error": repr(e)}
     dom = "mode0_contract" if kern["mode0_contract"]["ms"] >= kern["score"]["ms"] else "score"
+
+    ceilings = None
+    if not args.no_ceilings:
+        ceilings = measure_ceilings(be, timer, run.X2[0], X, J * K * es)
+        for name in ("mode0_contract", "score"):
+            kern[name]["frac_of_measured_read"] = kern[name]["GBps"] / ceilings["read_GBps"]
+        for name in rmw:
+            if "GBps" in kern[name]:
+                kern[name]["frac_of_measured_rmw"] = kern[name]["GBps"] / ceilings["rmw_GBps"]
+
     traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # from separate rocprofv3 --pmc passes (not live)
     if os.path.exists(pmc_file) and (I_total, J, K, world) == (65536, 128, 128, 1):
-        pmc = json.load(open(pmc_file))["kernels"]
+        doc = json.load(open(pmc_file))
         key = {"mode0_contract": "contract_vec_kernel", "score": "score_kernel"}[dom]
-        if key in pmc:
-            traffic, traffic_src = pmc[key]["hbm_bytes_per_launch"], "profiles/pmc_traffic.json"
+        if key in doc["kernels"]:
+            traffic = doc["kernels"][key]["hbm_bytes_per_launch"]
+            traffic_src = f"profiles/pmc_traffic.json ({doc.get('round', 'r01')}; separate rocprofv3 --pmc passes, not this run)"
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "alg_bytes_per_launch": xbytes, "avg_launch_ms": kern[dom]["ms"]}
+                "alg_bytes_per_launch": xbytes, "avg_launch_ms": kern[dom]["ms"],
+                "peak_measured_read": ceilings["read_GBps"] if ceilings else None,
+                "peak_measured_rmw": ceilings["rmw_GBps"] if ceilings else None,
+                "peak_measured_copy": ceilings["copy_GBps"] if ceilings else None,
+                "frac_of_measured_read": kern[dom]["GBps"] / ceilings["read_GBps"] if ceilings else None,
+                "ceilings": ceilings}
+
+    # the two per-iteration collectives (Z: J*K doubles, Y^T t: M doubles) of the eager pass
+    comm_info = None
+    if comm is not None:
+        by_size = {}
+        for e0, e1, nb in comm.pairs:
+            by_size.setdefault(nb, []).append(e0.elapsed_time(e1))
+        comm_info = {"backend": backend, "ranks": dist.get_world_size(), "forced_single_rank": force_dist,
+                     "allreduce_ms_by_bytes": {str(nb): sum(v) / len(v) for nb, v in sorted(by_size.items())},
+                     "allreduce_ms_per_step": sum(sum(v) for v in by_size.values()) / max(args.steps, 1),
+                     "collectives_per_step": len(comm.pairs) / max(args.steps, 1)}
     del Xw, Yw, run
 
     # ---- sec-to-fit leg (default tol / max_iter, like the reference's fit()) ----------------
     fit_info = None
+    mfma = None
     if not args.no_fit:
         Xf, Yf = X.clone(), Y.clone()
         torch.cuda.synchronize()
@@ -240,10 +384,6 @@ def main():
         # the same fit through the cross-covariance form (algorithm="xcov": S = X^T Y on the f64 matrix
         # cores, inner loop on S; exact re-association, one X read + one read/write per component)
         Xf, Yf = X.clone(), Y.clone()
-        timer.records["xcov"] = []
-        be.xcov = timer._wrap("xcov", be.xcov)
-        timer.on, timer.only = True, {"xcov"}     # bracket only the S build: markers on every tiny kernel of
-                                                  # the inner loop would perturb what is being timed
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -251,15 +391,9 @@ def main():
         sx = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov")
         torch.cuda.synchronize()
         xs = time.perf_counter() - t1
-        timer.on, timer.only = False, None
-        xms = timer.mean_ms("xcov")
         fit_info["xcov"] = {"seconds": xs, "n_iter": list(sx.n_iter), "iters_per_sec_in_fit": sum(sx.n_iter) / xs,
                             "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
-                            "max_abs_dT_vs_direct": float((sx.T - st.T).abs().max()),
-                            "xcov_kernel": {"ms": xms, "alg_GB": xbytes / 1e9, "GBps": xbytes / xms / 1e6,
-                                            "f64_mfma_TFLOPs": 2.0 * rows * J * K * M / xms / 1e9,
-                                            "frac_of_f64_mfma_peak_78.6TF": 2.0 * rows * J * K * M / xms / 1e9 / 78.6,
-                                            "mfma_utilisation_pmc": "profiles/r01i_mfma_utilisation.json"}}
+                            "max_abs_dT_vs_direct": float((sx.T - st.T).abs().max())}
         del Xf, Yf
         # opt-in mixed precision of the S build (f32 MFMA, csrc/mixed.hip): reported, never the headline
         Xf, Yf = X.clone(), Y.clone()
@@ -270,6 +404,20 @@ def main():
         fit_info["xcov_mixed_f32mfma"] = {"seconds": time.perf_counter() - t1, "n_iter": list(sm.n_iter),
                                           "max_abs_dT_vs_direct": float((sm.T - st.T).abs().max())}
         del Xf, Yf
+        # the two matrix-core kernels, WARM (workspaces sized, 1 untimed + 5 timed launches each): achieved HBM rate
+        # and matrix-pipe utilisation = flops / (time x 78.6 TF), the north star's "MFMA utilisation on the contraction"
+        X2 = X.view(rows, -1)
+        S = torch.empty(M, J * K, dtype=torch.float64, device=device)
+        Mo = torch.empty(rows, R, dtype=torch.float64, device=device)
+        WA, WB = st.blocks[0].loadings[0].contiguous(), st.blocks[0].loadings[1].contiguous()
+        mfma = {"peak_TF": F64_MFMA_PEAK_TF, "note": "f64 matrix cores (v_mfma_f64_16x16x4_f64); utilisation = flops / (avg launch time x peak)"}
+        for name, fn, flops in (("xcov", lambda: be.xcov(X2, Y, False, out=S), 2.0 * rows * J * K * M),
+                                ("mttkrp", lambda: be.mttkrp(X2, J, K, WA, WB, Mo), 2.0 * rows * J * K * 16 * ((R + 15) // 16))):
+            ms = timer.time_calls(fn, n=5, warm=1)
+            mfma[name] = {"ms": ms, "alg_GB": xbytes / 1e9, "GBps": xbytes / ms / 1e6, "TFLOPs": flops / ms / 1e9,
+                          "mfma_utilisation": flops / ms / 1e9 / F64_MFMA_PEAK_TF,
+                          "frac_of_measured_read": xbytes / ms / 1e6 / ceilings["read_GBps"] if ceilings else None}
+        mfma["mttkrp"]["note"] = "flops count the 16-wide MFMA tile the R=10 components occupy"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -286,12 +434,13 @@ def main():
             "config": {"workload": f"{cfg_name}: tPLS direct NIPALS iteration, X {I_total}x{J}x{K} f32 "
                                    f"(f64 accumulation), Y {I_total}x{M}, R={R}, noise {args.noise}",
                        "rows_per_gpu": rows, "parallelism": f"sample-mode shard x{world}" if world > 1 else "single GPU",
+                       "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
                        "x_reads_per_step": 2, "hip_graphs": bool(graphs_used), "graph_error": graph_error,
                        "eager_ms_per_step": eager_elapsed / args.steps * 1e3},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "fit": fit_info,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "collectives": comm_info, "mfma": mfma, "fit": fit_info,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if backend:
         dist.destroy_process_group()
 
 

@@ -550,7 +550,9 @@ __device__ __forceinline__ double dot_pack(const Pack<T, V>& x, const double* sB
 // GRAM: also the partial sums of Y^T t (tpls.py:100) of this workgroup's rows: lane m < M of every
 // wavefront accumulates t[i] * Y[i, m] over its rows, the wavefronts are added in index order and the
 // workgroup writes qpart[blockIdx.x, 0:M]; a small kernel adds the workgroups in index order.
-template <typename T, bool MASKED, bool VEC, bool GRAM>
+// GL: the loadings do not fit the LDS (A + B > 12 K doubles, e.g. a matrix block with > 12 K columns, A = 1):
+// they are read from global memory (L2-resident: at most a few hundred KB shared by every workgroup).
+template <typename T, bool MASKED, bool VEC, bool GRAM, bool GL = false>
 __global__ __launch_bounds__(kSweepThreads) __attribute__((amdgpu_waves_per_eu(5))) void score_kernel(
     const T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ wA,
     const double* __restrict__ wB, const double* __restrict__ rowcnt, double* __restrict__ t,
@@ -558,9 +560,9 @@ __global__ __launch_bounds__(kSweepThreads) __attribute__((amdgpu_waves_per_eu(5
   extern __shared__ double lds[];
   __shared__ double qs[kSweepThreads / kWave][kWave];
   double qacc = 0.0;
-  double* sA = lds;
-  double* sB = lds + ((A + 1) & ~1);
-  stage_loadings(sA, sB, wA, wB, A, B);
+  const double* sA = GL ? wA : lds;
+  const double* sB = GL ? wB : lds + ((A + 1) & ~1);
+  if (!GL) stage_loadings(lds, lds + ((A + 1) & ~1), wA, wB, A, B);
   constexpr int V = VEC ? VecOf<T>::N : 1;
   using VT = Pack<T, V>;
   const int lane = threadIdx.x & 63;
@@ -612,15 +614,15 @@ __global__ __launch_bounds__(kSweepThreads) __attribute__((amdgpu_waves_per_eu(5
 // ------------------------------------------------------------------------------------------
 // deflate: X[i,c] -= t[i] wA[c/B] wB[c%B]  (+ sum of squares of what is left)   wavefront per row
 // ------------------------------------------------------------------------------------------
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool GL = false>
 __global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
     T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ t,
     const double* __restrict__ wA, const double* __restrict__ wB, double* __restrict__ ssq_part) {
   extern __shared__ double lds[];
   __shared__ double red[16];
-  double* sA = lds;
-  double* sB = lds + ((A + 1) & ~1);
-  stage_loadings(sA, sB, wA, wB, A, B);
+  const double* sA = GL ? wA : lds;                    // GL: loadings too long for the LDS, read through L2
+  const double* sB = GL ? wB : lds + ((A + 1) & ~1);
+  if (!GL) stage_loadings(lds, lds + ((A + 1) & ~1), wA, wB, A, B);
   constexpr int V = VEC ? VecOf<T>::N : 1;
   using VT = Pack<T, V>;
   const int lane = threadIdx.x & 63;
@@ -931,11 +933,13 @@ static int run_score(const T* X, int64_t I, int A, int B, const double* wA, cons
   const bool gram = Y != nullptr;
   if (gram && (!qpart || M <= 0 || ldy < M)) { set_error("score_gram: bad argument"); return CMTFPLS_EINVAL; }
   if (gram && M > kWave) { set_error("score_gram: more than 64 responses; use score + gram_tn"); return CMTFPLS_EUNSUPPORTED; }
-  const size_t lds = loadings_lds_bytes(A, B);
-  if (lds > kMaxLoadingsLds) { set_error("score: A + B loadings exceed LDS; choose a more balanced (A, B) split"); return CMTFPLS_EUNSUPPORTED; }
+  size_t lds = loadings_lds_bytes(A, B);
+  const bool gl = lds > kMaxLoadingsLds;               // loadings longer than the LDS: read them through L2
+  if (gl) lds = 0;
   const bool v = vec_ok(X, B), m = rowcnt != nullptr;
   const dim3 g(kSweepBlocks), b(kSweepThreads);
-#define LAUNCH(MS, V, G) hipLaunchKernelGGL((score_kernel<T, MS, V, G>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart)
+#define LAUNCH(MS, V, G) do { if (gl) hipLaunchKernelGGL((score_kernel<T, MS, V, G, true>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart); \
+    else hipLaunchKernelGGL((score_kernel<T, MS, V, G, false>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart); } while (0)
   if (gram) { if (m && v) LAUNCH(true, true, true); else if (m) LAUNCH(true, false, true); else if (v) LAUNCH(false, true, true); else LAUNCH(false, false, true); }
   else      { if (m && v) LAUNCH(true, true, false); else if (m) LAUNCH(true, false, false); else if (v) LAUNCH(false, true, false); else LAUNCH(false, false, false); }
 #undef LAUNCH
@@ -947,8 +951,12 @@ static int run_deflate(T* X, int64_t I, int A, int B, const double* t, const dou
                        double* ssq_part, hipStream_t st) {
   if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("deflate: bad argument"); return CMTFPLS_EINVAL; }
   const size_t lds = loadings_lds_bytes(A, B);
-  if (lds > kMaxLoadingsLds) { set_error("deflate: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
   const dim3 g(kSweepBlocks), b(kSweepThreads);
+  if (lds > kMaxLoadingsLds) {                         // loadings longer than the LDS: read them through L2
+    if (vec_ok(X, B)) hipLaunchKernelGGL((deflate_kernel<T, true, true>), g, b, 0, st, X, I, A, B, t, wA, wB, ssq_part);
+    else hipLaunchKernelGGL((deflate_kernel<T, false, true>), g, b, 0, st, X, I, A, B, t, wA, wB, ssq_part);
+    return check_launch("deflate");
+  }
 #ifndef CMTFPLS_DEFLATE_ROWS
 #define CMTFPLS_DEFLATE_ROWS 1
 #endif

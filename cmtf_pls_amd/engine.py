@@ -23,6 +23,7 @@ tests inject a NumPy backend to exercise the sharded control flow under gloo on 
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -34,7 +35,9 @@ import torch
 class Comm:
     """Sample-mode data parallelism over torch.distributed (backend "nccl" = RCCL on ROCm)."""
 
-    def __init__(self, group=None, enabled: Optional[bool] = None):
+    def __init__(self, group=None, enabled: Optional[bool] = None, force: bool = False):
+        """force: take the sharded code path (collectives issued, segment-wise graph capture) even when the
+        group has a single rank -- how the one-GPU box exercises the RCCL calls of the engine."""
         import torch.distributed as dist
 
         self._dist = dist
@@ -42,15 +45,18 @@ class Comm:
         on = dist.is_available() and dist.is_initialized() if enabled is None else enabled
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
+        self.sharded = self.world > 1 or (bool(force) and on)
+        self.n_collectives = 0
 
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
+        if self.sharded:
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+            self.n_collectives += 1
         return t
 
 
 class _NoComm:
-    world, rank = 1, 0
+    world, rank, sharded = 1, 0, False
 
     def allreduce(self, t):
         return t
@@ -99,6 +105,15 @@ class NipalsEngine:
     def __init__(self, backend, comm=None):
         self.be = backend
         self.comm = comm if comm is not None else _NoComm()
+
+    def device_ctx(self):
+        """Make the backend's GPU the current HIP device for the duration of a call: the kernels are launched
+        through ctypes on that device's stream, so fitting on cuda:1 from a process whose current device is
+        cuda:0 must not depend on the caller having switched devices."""
+        dev = getattr(self.be, "device", None)
+        if isinstance(dev, torch.device) and dev.type == "cuda":
+            return torch.cuda.device(dev)
+        return contextlib.nullcontext()
 
     # ------------------------------------------------------------------------------------
     def _prepare_block(self, X: torch.Tensor, n_total: int) -> BlockState:
@@ -152,7 +167,8 @@ class NipalsEngine:
     def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool,
               algorithm: str = "direct") -> "FitRun":
         """Preprocess (centre in place) and allocate the per-fit buffers; see FitRun."""
-        return FitRun(self, Xs, Y, n_components, coupled, algorithm)
+        with self.device_ctx():
+            return FitRun(self, Xs, Y, n_components, coupled, algorithm)
 
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
             coupled: bool, verbose: int = 0, algorithm: str = "direct", use_graphs: bool = False,
@@ -160,25 +176,30 @@ class NipalsEngine:
         """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy.
         algorithm: "direct" = the reference's loop (two X reads per iteration); "xcov" = the same
         iteration re-associated through S = X_(0)^T Y (one X read + one read/write per component)."""
-        run = self.begin(Xs, Y, n_components, coupled, algorithm)
-        run.tol = tol                                            # also handed to parafac (tpls.py:86)
-        run.use_graphs = bool(use_graphs) and getattr(self.be, "name", "") == "hip"
-        run.mixed = bool(mixed)
-        for a in range(n_components):
-            run.start_component(a)
-            for it in range(max_iter):                           # tpls.py:79
-                du = run.iterate(it)
-                if du is not None and du < tol:                  # tpls.py:103 (first pass: oldU = inf)
-                    if verbose:
-                        print("Comp {}: converged after {} iterations".format(a, it))
-                    break
-            run.finish_component(a)
-        return run.result()
+        with self.device_ctx():
+            run = self.begin(Xs, Y, n_components, coupled, algorithm)
+            run.tol = tol                                            # also handed to parafac (tpls.py:86)
+            run.use_graphs = bool(use_graphs) and getattr(self.be, "name", "") == "hip"
+            run.mixed = bool(mixed)
+            for a in range(n_components):
+                run.start_component(a)
+                for it in range(max_iter):                           # tpls.py:79
+                    du = run.iterate(it)
+                    if du is not None and du < tol:                  # tpls.py:103 (first pass: oldU = inf)
+                        if verbose:
+                            print("Comp {}: converged after {} iterations".format(a, it))
+                        break
+                run.finish_component(a)
+            return run.result()
 
     # ------------------------------------------------------------------------------------
     def project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool = True, mixed: bool = False) -> torch.Tensor:
         """Sequential project-and-deflate of new samples (tpls.py:128-142; cmtf.py:143-177).
         Xs are device copies and are consumed.  Rows are independent: no communication."""
+        with self.device_ctx():
+            return self._project(state, Xs, one_pass, mixed)
+
+    def _project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool, mixed: bool) -> torch.Tensor:
         be = self.be
         R = state.n_components
         I = Xs[0].shape[0]
@@ -332,7 +353,7 @@ class FitRun:
             self.Gy = be.empty(M, M)
             self.qbuf = [be.zeros(M), be.zeros(M)]
             self.qpart = be.empty(len(self.blocks), int(be.n_partials) * M)
-        elif algorithm == "direct" and comm.world > 1:
+        elif algorithm == "direct" and comm.sharded:
             self.Gy = be.empty(M, M)
             self.q_prev = be.zeros(M)
         if algorithm == "xcov":
@@ -367,7 +388,7 @@ class FitRun:
             if self._fused:
                 self.qbuf[0].zero_()
                 self.qbuf[0][0] = 1.0                             # u_0 = Y[:, 0] = Y e_0 exactly
-            if self._fused or comm.world > 1:
+            if self._fused or comm.sharded:
                 be.gram_tn(self.Y, self.Y, out=self.Gy)
                 comm.allreduce(self.Gy)
             return
@@ -497,7 +518,7 @@ class FitRun:
         if self._fused:
             return self._iterate_fused(it)
         self._executed += 1
-        sharded = comm.world > 1
+        sharded = comm.sharded
         par = self._parity                       # which of the two u buffers holds the current u
         u, u_new = (self.u, self.u_new) if par == 0 else (self.u_new, self.u)
 
@@ -565,7 +586,7 @@ class FitRun:
         partial sums of Y^T t (92-100), and ONE small launch for q = sum / norm and |du|^2 (100-103)."""
         be, comm = self.eng.be, self.eng.comm
         self._executed += 1
-        sharded = comm.world > 1
+        sharded = comm.sharded
         par = self._parity
         q_cur, q_new = self.qbuf[par], self.qbuf[par ^ 1]
         nparts = len(self.blocks) * int(be.n_partials)
@@ -585,8 +606,11 @@ class FitRun:
             for b, blk in enumerate(self.blocks):
                 self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b], info=self.status[1 + 2 * b: 3 + 2 * b],
                                 n_squarings=self.sq_budget[b], fac=self.fac[b], tol=self.tol)
-                be.score_gram(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], blk.rowcnt if blk.has_miss else None,
-                              self.Ts[b], self.Y, self.qpart[b])
+                if be.score_gram(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], blk.rowcnt if blk.has_miss else None,
+                                 self.Ts[b], self.Y, self.qpart[b]) is None:
+                    # _fused is only chosen for M <= 64, the one shape limit of score_gram: anything else is a bug,
+                    # and q_update must not sum partial rows nobody wrote
+                    raise RuntimeError("score_gram refused a shape the fused iteration was planned for")
             if sharded:
                 be.q_update(q_new, self.qpart, normalize=False, nparts=nparts)   # local sum_b Y^T t_b; all-reduced next
 

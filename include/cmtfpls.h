@@ -226,6 +226,18 @@ int cmtfpls_y_deflate_f64(double* Y, int ldy, int M, int64_t I, const double* T,
                           void* stream);
 int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
 
+/* ---- measured HBM ceilings (the roofline denominator "re-measured with a device copy
+ * kernel"; not a reference call site) ---------------------------------------------------------------
+ * Plain 16-byte-per-lane non-temporal streaming kernels over `bytes` of a 16-byte-aligned buffer:
+ * read (sum kept in sink[0..blocks)), in-place read-modify-write (negates: two calls restore the data),
+ * copy src -> dst.  row_bytes == 0: flat map (consecutive workgroups adjacent, grid stride); row_bytes > 0
+ * (multiple of 16): a workgroup owns row_bytes contiguous bytes at a time, grid-striding over such rows
+ * (the map of the row-wise sweeps).  blocks <= cmtfpls_ceiling_max_blocks() workgroups of 256 threads. */
+int cmtfpls_ceiling_max_blocks(void);
+int cmtfpls_ceiling_read(const void* buf, size_t bytes, int64_t row_bytes, float* sink, int blocks, void* stream);
+int cmtfpls_ceiling_rmw(void* buf, size_t bytes, int64_t row_bytes, int blocks, void* stream);
+int cmtfpls_ceiling_copy(const void* src, void* dst, size_t bytes, int64_t row_bytes, int blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,37 @@ def reference_missingvals():
     print("ref_missingvals.npz:", sorted(out)[:6], "...")
 
 
+def decode_x128(code):
+    """int8 codes -> float64 X of ref_missingvals_128.npz: value = code / 16, code -128 = missing."""
+    x = code.astype(np.float64) / 16.0
+    x[code == -128] = np.nan
+    return x
+
+
+def reference_missingvals_bench_shape():
+    """The same two reference functions at the benchmark's trailing shape (J = K = 128, the column /
+    row lengths every BASELINE config but [4] uses), 30 % NaN as BASELINE configs[3].  X is stored as int8
+    codes (value = code / 16, exactly representable in f32 and f64; -128 = NaN) to keep the fixture small;
+    u and the loadings are stored as float64; outputs are the reference's."""
+    sys.path.insert(0, "/root/reference")
+    from cmtf_pls.missingvals import miss_mmodedot, miss_tensordot  # noqa: E402  (NumPy only)
+
+    rng = np.random.default_rng(20241004)
+    shape = (24, 128, 128)
+    code = rng.integers(-127, 128, size=shape).astype(np.int8)
+    code[rng.random(shape) < 0.30] = -128
+    code[:, 5, 77] = -128          # a column with no observation -> 0   (missingvals.py:18)
+    code[11] = -128                # a row with no observation    -> NaN (missingvals.py:37)
+    X = decode_x128(code)
+    u = rng.normal(size=shape[0])
+    facs = [rng.normal(size=d) for d in shape[1:]]
+    with np.errstate(all="ignore"):
+        out = dict(code=code, u=u, w0=facs[0], w1=facs[1], tensordot=miss_tensordot(X, u, np.isnan(X)),
+                   mmodedot=miss_mmodedot(X, facs, np.isnan(X)))
+    np.savez_compressed(os.path.join(HERE, "ref_missingvals_128.npz"), **out)
+    print("ref_missingvals_128.npz written")
+
+
 def _pack(fit, prefix=""):
     d = {prefix + "T": fit.T, prefix + "U": fit.U, prefix + "Q": fit.Q, prefix + "coef": fit.coef,
          prefix + "r2y": fit.r2y, prefix + "y_mean": fit.y_mean, prefix + "n_iter": np.array(fit.n_iter)}
@@ -102,4 +133,5 @@ def oracle_regression():
 
 if __name__ == "__main__":
     reference_missingvals()
+    reference_missingvals_bench_shape()
     oracle_regression()

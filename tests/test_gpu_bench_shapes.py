@@ -1,0 +1,180 @@
+"""Fit-level parity at the BENCHMARK's trailing shapes (VERDICT r1 "What's weak" #4, SURVEY 8(d): "parity at
+scale is GPU-vs-CPU-restatement on a row-subsampled replica").
+
+The kernels the benchmark shapes select -- KC / FULL score_deflate variants, the 1024-thread deflate_rows path,
+the parked-LDS half row at P = 65536, "u = Y q up front" for >= 16 column tiles, xcov / MTTKRP with M = 32 and
+two response tiles -- are only reached with J = K = 128 or 256.  Here whole fits (direct AND xcov, coupled,
+30 % NaN) at exactly those trailing shapes, with fewer rows so that the float64 oracle finishes in seconds,
+are compared with the oracle value by value.
+
+Tolerance (north star: "factors matching the CPU reference to rtol=1e-5"): f32 storage of f32-representable
+inputs, every sum in f64; scores / loadings / q within 1e-5 of the oracle's, relative to each component's
+own scale (column-wise max), loadings after the per-component paired sign.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def api():
+    import cmtf_pls_amd
+    return cmtf_pls_amd
+
+
+def _f32(a):
+    return a.astype(np.float32).astype(np.float64)
+
+
+def col_close(got, want, rtol=RTOL, sign=None):
+    """|got - want| <= rtol * (|want| + max|column|), column by column (normwise per component)."""
+    if sign is not None:
+        got = got * sign
+    scale = np.abs(want).max(axis=0, keepdims=True)
+    err = np.abs(got - want) / (np.abs(want) + scale)
+    assert err.max() <= rtol, f"max column-relative error {err.max():.3e} > {rtol:.0e} (component {int(err.max(axis=0).argmax())})"
+    return err.max()
+
+
+def check_fit(m, fit, block=0, rtol=RTOL):
+    Xf = m.X_factors if hasattr(m, "X_factors") else m.Xs_factors[block]
+    col_close(Xf[0], fit.T, rtol)
+    loads = fit.loadings[block]
+    s = np.sign(np.sum(Xf[1] * loads[0], axis=0))
+    s[s == 0] = 1
+    for mode, L in enumerate(loads):
+        col_close(Xf[1 + mode], L, rtol, sign=s if len(loads) == 2 else None)
+    col_close(m.Y_factors[1], fit.Q, rtol)
+    col_close(m.Y_factors[0], fit.U, rtol)
+    assert_allclose(m.R2Y, fit.r2y, rtol=rtol, atol=rtol)
+    r2x = m.R2X if hasattr(m, "R2X") else m.R2Xs[block]
+    assert_allclose(r2x, fit.r2x[block], rtol=rtol, atol=rtol)
+    assert_allclose(m.coef_, fit.coef, rtol=10 * rtol, atol=10 * rtol * np.abs(fit.coef).max())
+    assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
+
+
+# ---- (4096, 128, 128), M = 16: BASELINE configs[1] with 1/16 of the rows -----------------------------
+@pytest.fixture(scope="module")
+def cfg2_replica():
+    x, y, cp = O.import_synthetic((4096, 128, 128), 16, 10, error=0.1, seed=215)
+    x, y = _f32(x), _f32(y)
+    return x, y, cp, O.fit_tpls(x, y, 3, max_iter=25)
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_cfg2_replica_fit_vs_oracle(api, cfg2_replica, algorithm):
+    x, y, _, fit = cfg2_replica
+    m = api.tPLS(3, dtype="float32", algorithm=algorithm)
+    m.fit(x, y, max_iter=25)
+    check_fit(m, fit)
+    # transform / predict at this shape: one-pass MTTKRP and, with a NaN planted, the sequential score_deflate path
+    T = m.transform(x[:512])
+    col_close(T, O.transform(fit, x[:512]))
+    xt = x[:256].copy()
+    xt[3, 5, 7] = np.nan
+    col_close(m.transform(xt), O.transform(fit, xt))
+    assert_allclose(m.predict(x[:512]), O.predict(fit, x[:512]), rtol=1e-5, atol=1e-5 * np.abs(y).max())
+
+
+def test_cfg2_replica_graph_replay(api, cfg2_replica):
+    x, y, _, fit = cfg2_replica
+    g = api.tPLS(3, dtype="float32", graphs=True)
+    g.fit(x, y, max_iter=25)
+    check_fit(g, fit)
+
+
+# ---- (1024, 256, 256), M = 32: BASELINE configs[4] with 1/256 of the rows ----------------------------
+@pytest.fixture(scope="module")
+def cfg5_replica():
+    x, y, _ = O.import_synthetic((1024, 256, 256), 32, 10, error=0.1, seed=215)
+    x, y = _f32(x), _f32(y)
+    return x, y, O.fit_tpls(x, y, 3, max_iter=20)
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_cfg5_replica_fit_vs_oracle(api, cfg5_replica, algorithm):
+    x, y, fit = cfg5_replica
+    m = api.tPLS(3, dtype="float32", algorithm=algorithm)
+    m.fit(x, y, max_iter=20)
+    check_fit(m, fit)
+    col_close(m.transform(x[:256]), O.transform(fit, x[:256]))
+    xt = x[:64].copy()
+    xt[1, 2, 3] = np.nan                                         # sequential path: score_deflate with the parked half row
+    col_close(m.transform(xt), O.transform(fit, xt))
+
+
+# ---- coupled: tensor (1024, 128, 128) + matrix (1024, 512) sharing the sample mode (configs[2]) -----------
+@pytest.fixture(scope="module")
+def cfg3_replica():
+    x, y, cp = O.import_synthetic((1024, 128, 128), 16, 10, error=0.1, seed=215)
+    xm = cp.factors[0] @ np.random.default_rng(216).normal(size=(512, 10)).T + 0.1 * np.random.default_rng(5).normal(size=(1024, 512))
+    x, xm, y = _f32(x), _f32(xm), _f32(y)
+    return x, xm, y, O.fit_ctpls([x, xm], y, 3, max_iter=25)
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_cfg3_replica_coupled_vs_oracle(api, cfg3_replica, algorithm):
+    x, xm, y, fit = cfg3_replica
+    m = api.ctPLS(3, dtype="float32", algorithm=algorithm)
+    m.fit([x, xm], y, max_iter=25)
+    check_fit(m, fit, block=0)
+    check_fit(m, fit, block=1)
+    col_close(m.transform([x[:256], xm[:256]]), O.transform(fit, [x[:256], xm[:256]]))
+
+
+# ---- 30 % NaN at 128 x 128 (configs[3]) ----------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cfg4_replica():
+    x, y, _ = O.import_synthetic((1024, 128, 128), 16, 10, error=0.1, seed=215)
+    x, y = _f32(x), _f32(y)
+    x[np.random.default_rng(217).random(x.shape) < 0.3] = np.nan
+    return x, y, O.fit_tpls(x, y, 3, max_iter=25)
+
+
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_cfg4_replica_nan30_vs_oracle(api, cfg4_replica, algorithm):
+    x, y, fit = cfg4_replica
+    m = api.tPLS(3, dtype="float32", algorithm=algorithm)
+    m.fit(x, y, max_iter=25)
+    assert m.X_hasMiss
+    check_fit(m, fit)
+    col_close(m.transform(x[:256]), O.transform(fit, x[:256]))
+
+
+# ---- BASELINE configs[4] at FULL size on one GPU through size-independent properties ---------------------
+def test_cfg5_full_size_properties(api):
+    """X 262144 x 256 x 256 f32 (68.7 GB), Y 262144 x 32: direct == xcov (two different kernel sets: sweeps with
+    "u up front" vs. S on the matrix cores with two response tiles + carried S), unit-norm loadings, monotone R2,
+    transform(training X) == training scores (one-pass MTTKRP over 68.7 GB), R2X against the literal
+    reconstruction formula on a row sample."""
+    import torch
+    from cmtf_pls_amd.synthetic import synthetic_shard_device
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~140 GB of free HBM")
+    X, Y = synthetic_shard_device((262144, 256, 256), 32, 10, error=0.1, device="cuda:0")
+    m = api.tPLS(2, dtype="float32")
+    m.fit(X, Y, max_iter=12)
+    xc = api.tPLS(2, dtype="float32", algorithm="xcov")
+    xc.fit(X, Y, max_iter=12)
+    assert m.n_iter_ == xc.n_iter_
+    col_close(xc.X_factors[0], m.X_factors[0])
+    assert_allclose(xc.R2X, m.R2X, rtol=1e-6)
+    assert_allclose(xc.R2Y, m.R2Y, rtol=1e-6)
+    for f in m.X_factors[1:]:
+        assert_allclose(np.linalg.norm(f, axis=0), 1, rtol=1e-12)
+    assert np.all(np.diff(m.R2X) > 0) and np.all(np.diff(m.R2Y) > 0)
+    s = np.abs(m.X_factors[0]).max()
+    assert_allclose(m.transform(X), m.X_factors[0], rtol=1e-4, atol=1e-5 * s)
+    rows = torch.arange(0, 262144, 256, device="cuda:0")          # 1024 rows
+    Xs = X[rows].double() - torch.from_numpy(m.X_mean).cuda()
+    Tsub = torch.from_numpy(m.X_factors[0]).cuda()[rows]
+    rec = torch.einsum("ir,jr,kr->ijk", Tsub, torch.from_numpy(m.X_factors[1]).cuda(), torch.from_numpy(m.X_factors[2]).cuda())
+    r2_sample = 1 - float(((Xs - rec) ** 2).sum()) / float((Xs ** 2).sum())
+    assert abs(r2_sample - m.R2X[-1]) < 1e-2

@@ -72,3 +72,16 @@ def test_inner_loop_is_the_fit_trajectory():
     np.testing.assert_allclose(t, fit.T[:, 0], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(q, fit.Q[:, 0], rtol=1e-12, atol=1e-12)
     assert du < 1e-8
+
+
+def test_oracle_matches_reference_at_benchmark_trailing_shape(golden_dir):
+    """ref_missingvals_128.npz: the reference's two masked contractions at J = K = 128 with 30 % NaN
+    (BASELINE configs[3]'s mask density), an empty column and an empty row (tests/golden/make_golden.py)."""
+    from golden.make_golden import decode_x128
+    g = np.load(os.path.join(golden_dir, "ref_missingvals_128.npz"))
+    X = decode_x128(g["code"])
+    np.testing.assert_allclose(O.masked_mode0_contract(X, g["u"], np.isnan(X)), g["tensordot"], rtol=1e-12, atol=1e-13)
+    got, want = O.masked_score(X, [g["w0"], g["w1"]], np.isnan(X)), g["mmodedot"]
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want[11])
+    np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=1e-12, atol=1e-13)
+    assert g["tensordot"][5, 77] == 0.0
