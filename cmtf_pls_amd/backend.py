@@ -271,6 +271,49 @@ class HipBackend:
                                                _ptr(ws), ws.numel(), self._stream()), "rowdot")
         return du2 if u_old is not None else None
 
+    # -- component epilogue / projection fix-up / reconstruction without a host round trip --------
+    def normal_solve(self, G: torch.Tensor, g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """b = argmin |T b - u| from G = T^T T (k x k), g = T^T u: lstsq(T, u, rcond=-1) of tpls.py:110-112."""
+        k = G.shape[0]
+        assert G.is_contiguous() and G.shape == (k, k) and g.numel() == k
+        b = out if out is not None else self.empty(k)
+        _lib.check(self.lib.cmtfpls_normal_solve_f64(_ptr(G), _ptr(g), k, _ptr(b), 1, self._stream()), "normal_solve")
+        return b
+
+    def unit_upper_solve_rows(self, M: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
+        """Rows of M (I x R) overwritten by the rows of T solving T (I + triu(U, 1)) = M."""
+        I, R = M.shape
+        assert M.stride(1) == 1 and U.is_contiguous() and U.shape == (R, R)
+        _lib.check(self.lib.cmtfpls_unit_upper_solve_rows_f64(_ptr(M), I, M.stride(0), R, _ptr(U), self._stream()), "unit_upper_solve_rows")
+        return M
+
+    def kr_gram(self, L: torch.Tensor, G: torch.Tensor, first: bool) -> torch.Tensor:
+        """G = L^T L (first) or G .*= L^T L: Gram of a Khatri-Rao product, one mode at a time."""
+        n, R = L.shape
+        assert L.is_contiguous() and G.is_contiguous() and G.numel() == R * R
+        _lib.check(self.lib.cmtfpls_kr_gram_f64(_ptr(L), n, R, _ptr(G), int(first), 1.0, self._stream()), "kr_gram")
+        return G
+
+    def khatri_rao(self, Am: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
+        na, R = Am.shape
+        nb = Bm.shape[0]
+        assert Am.is_contiguous() and Bm.is_contiguous() and Bm.shape[1] == R
+        out = self.empty(na * nb, R)
+        _lib.check(self.lib.cmtfpls_khatri_rao_f64(_ptr(Am), na, _ptr(Bm), nb, R, _ptr(out), self._stream()), "khatri_rao")
+        return out
+
+    def recon(self, T: torch.Tensor, WA: torch.Tensor, WB: torch.Tensor, mean: Optional[torch.Tensor], out: torch.Tensor) -> Optional[torch.Tensor]:
+        """out (I, A*B) = T (WA (.) WB)^T + mean in out's dtype (factors_to_tensor util.py:18-20 + X_mean);
+        None when the shape is outside the vector form (caller falls back to the host einsum)."""
+        I, R = T.shape
+        A, B = WA.shape[0], WB.shape[0]
+        assert T.stride(1) == 1 and WA.is_contiguous() and WB.is_contiguous() and out.is_contiguous() and out.numel() == I * A * B
+        rc = self._fn("recon", out)(_ptr(T), I, T.stride(0), R, _ptr(WA), _ptr(WB), A, B, _ptr(mean), _ptr(out), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "recon")
+        return out
+
     def scores_mean(self, Ts: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         nb, I = Ts.shape
         _lib.check(self.lib.cmtfpls_scores_mean_f64(_ptr(Ts), nb, I, _ptr(out), self._stream()), "scores_mean")

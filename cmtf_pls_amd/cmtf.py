@@ -55,7 +55,8 @@ class ctPLS(_EstimatorBase):
         self.Xs_hasMiss = [blk.has_miss for blk in st.blocks]
         if any(self.Xs_hasMiss):
             print("At least one X has missing values")                    # cmtf.py:78-79
-        self._Xs_in, self._Xs_miss = Xs, None     # Xs_miss (cmtf.py:80-82) is built on first access
+        # kept by reference for the lazy Xs_miss (cmtf.py:80-82); with copy_X=False the blocks were fitted in place
+        self._Xs_in, self._Xs_miss = (Xs if self._copy_X else [None] * len(Xs)), None
         self.n_iter_ = list(st.n_iter)
 
     @property
@@ -84,7 +85,5 @@ class ctPLS(_EstimatorBase):
             return X_scores, self._y_scores(X_scores, Y)
         return X_scores
 
-    def Xs_reconstructed(self):
-        from .util import factors_to_tensor
-
-        return [factors_to_tensor(self.Xs_factors[ti]) + self.Xs_mean[ti] for ti in range(self.Xs_len)]
+    def Xs_reconstructed(self, rows=None, device: bool = False):
+        return [self._reconstruct(ti, self.Xs_factors[ti], self.Xs_mean[ti], rows, device) for ti in range(self.Xs_len)]   # cmtf.py:233-237

@@ -17,7 +17,6 @@ namespace cmtfpls {
 constexpr int kTile = 16;
 constexpr int kMaxTiles = 64;   // n <= 1024
 constexpr int kMaxSteps = 48;
-constexpr int kPanelK = 256;    // k-chunk staged in LDS per pass
 
 struct Rank1Ctl {
   double trace[kMaxSteps + 2][kMaxTiles];  // trace[s][tile]: diagonal-tile partial traces of G_s
@@ -25,7 +24,7 @@ struct Rank1Ctl {
   int done;                                // set once G is numerically rank one
   int final_buf;                           // which ping-pong buffer holds the final G
   int steps_used;                          // squarings actually computed
-  int pad;
+  int last_step;                           // >= 0: the output of this step is the final G (set by that step itself)
 };
 
 __device__ __forceinline__ double pow2_scale_from_trace(const double* parts, int nt, double* tr_out) {
@@ -38,60 +37,71 @@ __device__ __forceinline__ double pow2_scale_from_trace(const double* parts, int
   return ldexp(1.0, -e);    // exact power of two
 }
 
+typedef double d4r_t __attribute__((ext_vector_type(4)));
+
 // C = s^2 * M M^T for row-major M (n x k, leading dim ld); s is the power-of-two scale derived from
 // the trace of the input (step >= 1) or 1 (step 0, the Gram matrix of Z itself).
+//
+// One workgroup (4 wavefronts) per 16 x 16 tile of C on the f64 matrix cores, operands straight from
+// global memory into registers in the MFMA layout (no LDS staging):
+//   v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][kq = l >> 4] and B[kq][j = l & 15] and holds
+//   D[(l >> 4) + 4 e][l & 15], e = 0..3.
+//   A k-chunk is 128 columns; wavefront w takes columns [32 w, 32 w + 32) of it, lane group kq the 8
+//   consecutive columns 32 w + 8 kq + (0..7): MFMA s of the chunk multiplies column 32 w + 8 kq + s of
+//   row i0 + (l & 15) with the same column of row j0 + (l & 15) (B = M^T: B[kq][j] = M[j0 + j][column]).
+//   The 4 wavefronts' partial tiles are added in wavefront order through LDS: the summation order is fixed
+//   (bit-reproducible), and tile (i, j) is bitwise the transpose of tile (j, i) (same products, same order).
 // A step is a chain of memory latencies (the previous step's output lives in another XCD's L2), so the
-// kernel issues the loads of its two 16 x 256 panels first, into registers, and only then reads the
-// control block (traces, Frobenius partials) that decides the scale and the early exit: one latency per
-// step instead of three, and no load waits behind another.
+// kernel issues the 16 operand loads of its first chunk first and only then reads the control block (traces,
+// Frobenius partials) that decides the scale and the early exit: one latency per step instead of three.
+//
+// Convergence (step >= 1, from the INPUT G_{s-1}): rho = tr(G^2) / tr(G)^2 = 1 - 2 (lambda_2/lambda_1) to first
+// order.  rho >= 1 - 1e-13: the input is rank one to 5e-14 and is taken as the result (this launch and the
+// later ones return at once).  rho >= 1 - 1e-7: the input's ratio is <= 5e-8, so THIS step's output has ratio
+// <= 2.5e-15: the product is computed and declared final (ctl->done), which saves the launch that would only
+// have detected it.  In both cases the dominant column still goes through one exact pass with Z afterwards.
 __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* __restrict__ M, int n, int k, int ld,
                                                                 double* __restrict__ C, Rank1Ctl* __restrict__ ctl,
                                                                 int step, int out_buf) {
-  extern __shared__ double panel[];       // As[16][kc+1] then Bs[16][kc+1]
+  __shared__ double red[4][kTile * kTile];
   __shared__ double diag[kTile];
   __shared__ double s_scale;
   __shared__ int s_done;
   __shared__ double fsum[4];
   __shared__ double tr_s[kMaxTiles];
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTile + tx;
+  const int lane = tid & 63, wv = tid >> 6, ri = lane & 15, kq = lane >> 4;
   const int nt = (n + kTile - 1) / kTile;
   const int i0 = blockIdx.y * kTile, j0 = blockIdx.x * kTile;
 
-  // (1) first k-chunk of both panels: thread (ty, tx) owns row ty, columns tx + 16 u.  Loads are
-  // unconditional (clamped address, select afterwards) so that all of them are in flight together.
-  constexpr int PU = kPanelK / kTile / 2;            // 8 loads per panel per batch, two batches
-  const int kc0 = (k < kPanelK) ? k : kPanelK;
-  const bool ra = (i0 + ty) < n, rb = (j0 + ty) < n;
-  const double* __restrict__ rowa = M + (int64_t)(ra ? i0 + ty : 0) * ld;
-  const double* __restrict__ rowb = M + (int64_t)(rb ? j0 + ty : 0) * ld;
-  double pa[2][PU], pb[2][PU];
+  // (1) operands of the first k-chunk: unconditional loads (clamped address, select afterwards) so that
+  // all 16 are in flight together
+  constexpr int KC = 128, KW = 8;                     // chunk width; columns per lane per chunk
+  const bool ra = (i0 + ri) < n, rb = (j0 + ri) < n;
+  const double* __restrict__ rowa = M + (int64_t)(ra ? i0 + ri : 0) * ld;
+  const double* __restrict__ rowb = M + (int64_t)(rb ? j0 + ri : 0) * ld;
+  const int cl = 32 * wv + KW * kq;                   // this lane's first column inside a chunk
+  double a[KW], b[KW];
 #pragma unroll
-  for (int u = 0; u < PU; ++u) {
-    const int c = tx + kTile * u;
-    const int cc = (c < kc0) ? c : 0;
-    pa[0][u] = rowa[cc];                             // masked when written to LDS, not here: a select
-    pb[0][u] = rowb[cc];                             // next to the load becomes a branch around it
-  }
-  const bool wide = kc0 > kTile * PU;                // uniform: a second batch of columns exists
-  if (wide) {
-#pragma unroll
-    for (int u = 0; u < PU; ++u) {
-      const int c = tx + kTile * (PU + u);
-      const int cc = (c < kc0) ? c : 0;
-      pa[1][u] = rowa[cc];
-      pb[1][u] = rowb[cc];
-    }
+  for (int s2 = 0; s2 < KW; ++s2) {
+    const int c = cl + s2;
+    const int cc = (c < k) ? c : 0;
+    a[s2] = rowa[cc];
+    b[s2] = rowb[cc];
   }
 
   // (2) control: scale from the input's trace, early exit once the input is numerically rank one.
-  // The control words are vector loads issued right behind the panel loads (same single wait).
+  // The control words are vector loads issued right behind the operand loads (same single wait).
   double fro_in = 0.0;
   if (step >= 1) {
     // the flag's address is laundered into a VGPR so that this is a vector load in the same batch as
     // the others (as a scalar load the compiler issues it after the wait: a second latency)
     int zero = 0;
     asm volatile("" : "+v"(zero));
-    const int done_in = (&ctl->done)[zero];
+    // done: an earlier launch found its input rank one.  last_step = s0 < step: step s0 declared its own output
+    // final.  (A workgroup of step s0 itself may see last_step == s0, written by a sibling: it still computes.)
+    const int last_in = (&ctl->last_step)[zero];
+    const int done_in = (&ctl->done)[zero] | ((last_in >= 0 && last_in < step) ? 1 : 0);
     const double* fp = ctl->fro[(step - 1) & 1];
     const double trv = ctl->trace[step - 1][(tid < nt) ? tid : 0];
     // |G_{s-1}|_F^2 from the per-tile sums the previous step left (fixed order: bit-reproducible)
@@ -109,22 +119,24 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
     int done = 0;
     double scale = 1.0;
     if (step == 0) {
-      if (blockIdx.x == 0 && blockIdx.y == 0) { ctl->done = 0; ctl->final_buf = -1; ctl->steps_used = 0; }
+      if (blockIdx.x == 0 && blockIdx.y == 0) { ctl->done = 0; ctl->final_buf = -1; ctl->steps_used = 0; ctl->last_step = -1; }
     } else {
       done = s_done;
       if (!done) {
         // G_s = (sc_{s-1} G_{s-1})^2 with sc_{s-1} the power-of-two scale of tr(G_{s-1}).
         double tr1;
         scale = pow2_scale_from_trace(tr_s, nt, &tr1);
-        // rho = tr(G^2) / tr(G)^2 of the INPUT G_{s-1} is 1 - 2*(lambda_2/lambda_1) to first order:
-        // at 1 - 1e-13 the input is rank one to 5e-14 and is taken as the result (its dominant column
-        // then still goes through one exact pass with Z in the finish kernels).
         const double rho = fro_in / (tr1 * tr1);
-        if (!(tr1 > 0.0) || rho >= 1.0 - 1e-13) done = 1;
+        const bool rank_one_in = !(tr1 > 0.0) || rho >= 1.0 - 1e-13;     // the input already is the result
+        const bool rank_one_out = rho >= 1.0 - 1e-7;                      // this step's output will be
         if (blockIdx.x == 0 && blockIdx.y == 0) {
-          if (done) { ctl->done = 1; ctl->final_buf = out_buf ^ 1; }
-          else ctl->steps_used = step;
+          if (rank_one_in) { ctl->done = 1; ctl->final_buf = out_buf ^ 1; }
+          else {
+            ctl->steps_used = step;
+            if (rank_one_out) { ctl->last_step = step; ctl->final_buf = out_buf; }
+          }
         }
+        if (rank_one_in) done = 1;
       }
     }
     s_scale = scale;
@@ -134,53 +146,44 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   if (s_done) return;
   const double scale = s_scale;
 
-  // (3) the product, k-chunk by k-chunk (one chunk whenever k <= 256: every squaring of the
-  // benchmark shapes); the summation order over k is ascending, as a plain dot product
-  double acc = 0.0;
-  for (int kk = 0; kk < k; kk += kPanelK) {
-    const int kc = (k - kk < kPanelK) ? k - kk : kPanelK;
-    const int ldp = kc + 1;
-    double* As = panel;
-    double* Bs = panel + kTile * ldp;
-    if (kk == 0) {
+  // (3) the product, chunk by chunk (one chunk whenever k <= 128: every squaring of a 128 x 128 Z)
+  d4r_t acc = d4r_t{0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < k; kk += KC) {
+    if (kk > 0) {
 #pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        const int c = tx + kTile * u;
-        if (c < kc) { As[ty * ldp + c] = ra ? pa[0][u] : 0.0; Bs[ty * ldp + c] = rb ? pb[0][u] : 0.0; }
-      }
-      if (wide) {
-#pragma unroll
-        for (int u = 0; u < PU; ++u) {
-          const int c = tx + kTile * (PU + u);
-          if (c < kc) { As[ty * ldp + c] = ra ? pa[1][u] : 0.0; Bs[ty * ldp + c] = rb ? pb[1][u] : 0.0; }
-        }
-      }
-    } else {
-      for (int c = tx; c < kc; c += kTile) {
-        As[ty * ldp + c] = ra ? rowa[kk + c] : 0.0;
-        Bs[ty * ldp + c] = rb ? rowb[kk + c] : 0.0;
+      for (int s2 = 0; s2 < KW; ++s2) {
+        const int c = kk + cl + s2;
+        const int cc = (c < k) ? c : 0;
+        a[s2] = rowa[cc];
+        b[s2] = rowb[cc];
       }
     }
-    __syncthreads();
-    const double* ar = As + ty * ldp;
-    const double* br = Bs + tx * ldp;
-#pragma unroll 8
-    for (int l = 0; l < kc; ++l) acc = fma(ar[l], br[l], acc);
-    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < KW; ++s2) {
+      const bool cok = (kk + cl + s2) < k;
+      const double av = (ra && cok) ? a[s2] : 0.0;
+      const double bv = (rb && cok) ? b[s2] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
   }
-  acc *= scale * scale;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wv][(kq + 4 * e) * kTile + ri] = acc[e];
+  __syncthreads();
+  // thread (ty, tx) closes element (row ty, column tx) of the tile
+  double cacc = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  cacc *= scale * scale;
   const bool inside = (i0 + ty < n && j0 + tx < n);
-  if (inside) C[(int64_t)(i0 + ty) * n + (j0 + tx)] = acc;
+  if (inside) C[(int64_t)(i0 + ty) * n + (j0 + tx)] = cacc;
   {
     // this tile's contribution to |G_s|_F^2
-    double sq = inside ? acc * acc : 0.0;
+    double sq = inside ? cacc * cacc : 0.0;
     sq = wave_sum(sq);
     if ((tid & 63) == 0) fsum[tid >> 6] = sq;   // fsum is free: its readers passed two barriers since
     __syncthreads();
     if (tid == 0) ctl->fro[step & 1][blockIdx.y * nt + blockIdx.x] = ((fsum[0] + fsum[1]) + fsum[2]) + fsum[3];
   }
   if (blockIdx.x == blockIdx.y) {
-    if (tx == ty) diag[tx] = (i0 + ty < n) ? acc : 0.0;
+    if (tx == ty) diag[tx] = (i0 + ty < n) ? cacc : 0.0;
     __syncthreads();
     if (tid == 0) {
       double t = 0.0;
@@ -311,7 +314,7 @@ __device__ __forceinline__ void rank1_final_body(const double* x, const double* 
   if (threadIdx.x == 0) {
     // y = M^T seed has norm ~ sigma, x = M y has norm ~ sigma^2: sigma_1 = |x| / |y|
     if (sigma) sigma[0] = nx / ny;
-    if (info) { info[0] = ctl->done ? 1.0 : 0.0; info[1] = (double)ctl->steps_used; }
+    if (info) { info[0] = (ctl->done || ctl->last_step >= 0) ? 1.0 : 0.0; info[1] = (double)ctl->steps_used; }
   }
 }
 
@@ -367,13 +370,12 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
   }
   const int nt = (n + kTile - 1) / kTile;
   const dim3 grid(nt, nt), block(kTile, kTile);
-  auto panel_lds = [](int kdim) { const int kc = kdim < kPanelK ? kdim : kPanelK; return (size_t)2 * kTile * (kc + 1) * sizeof(double); };
   // step 0: G_0 = M0 M0^T -> buf0 ; step s: G_s = scale^2 G_{s-1} G_{s-1}^T -> buf[s & 1]
-  hipLaunchKernelGGL(syrk_step_kernel, grid, block, panel_lds(k), st, M0, n, k, k, buf0, ctl, 0, 0);
+  hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, M0, n, k, k, buf0, ctl, 0, 0);
   for (int s = 1; s <= n_squarings; ++s) {
     const double* in = (s & 1) ? buf0 : buf1;
     double* out = (s & 1) ? buf1 : buf0;
-    hipLaunchKernelGGL(syrk_step_kernel, grid, block, panel_lds(n), st, in, n, n, n, out, ctl, s, s & 1);
+    hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, in, n, n, n, out, ctl, s, s & 1);
   }
   // (a single-workgroup fusion of the three finish kernels was measured: no faster than these three
   // parallel launches, so the epilogue stays split)

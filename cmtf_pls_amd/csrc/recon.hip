@@ -1,0 +1,97 @@
+// K8: factors_to_tensor (cmtf_pls/util.py:18-20) as used by X_reconstructed (tpls.py:188-189, cmtf.py:233-237):
+//   Xhat[i, c] = sum_r T[i, r] * WA[c / B, r] * WB[c % B, r]  (+ mean[c])
+// for a block of rows, written in the storage type of X.  The reference forms T . khatri_rao(...)^T as a dense
+// GEMM on the host (8.6 GB of float64 at 65536 x 128 x 128); here the Khatri-Rao operand is never materialised:
+// a thread owns V consecutive columns (16 bytes of output), keeps their R loading products in registers and
+// loops over the rows of its row block; the score row T[i, :] is workgroup-uniform (scalar loads).
+// The kernel is write-bound (I * P * s bytes out, R f64 FMAs per element: 10 FMAs against 4 bytes).
+#include "common.hpp"
+
+namespace cmtfpls {
+
+constexpr int kReconMaxR = 16;   // components per pass (register budget); more are accumulated in passes
+
+template <typename T, int RC>
+__global__ __launch_bounds__(kSweepThreads) void recon_kernel(const double* __restrict__ Tm, int ldt, int r0, int R,
+                                                             const double* __restrict__ WA, const double* __restrict__ WB, int B,
+                                                             const double* __restrict__ mean, T* __restrict__ out, int64_t I, int64_t P,
+                                                             int rows_per_block, int accumulate) {
+  constexpr int V = VecOf<T>::N;
+  using VT = typename VecOf<T>::type;
+  const int64_t c = ((int64_t)blockIdx.x * kSweepThreads + threadIdx.x) * V;
+  if (c >= P) return;
+  const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t i1 = (i0 + rows_per_block < I) ? i0 + rows_per_block : I;
+  double w[RC][V], mu[V];
+  const int j = (int)(c / B), k = (int)(c % B);          // B % V == 0: one j for the whole vector
+#pragma unroll
+  for (int r = 0; r < RC; ++r)
+#pragma unroll
+    for (int e = 0; e < V; ++e) w[r][e] = (r0 + r < R) ? WA[(int64_t)j * R + r0 + r] * WB[(int64_t)(k + e) * R + r0 + r] : 0.0;
+#pragma unroll
+  for (int e = 0; e < V; ++e) mu[e] = (mean && !accumulate) ? mean[c + e] : 0.0;
+  for (int64_t i = i0; i < i1; ++i) {
+    const double* __restrict__ trow = Tm + i * ldt + r0;
+    double acc[V];
+    VT o;
+    if (accumulate) {
+      o = *reinterpret_cast<const VT*>(out + i * P + c);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = (double)o.e[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = mu[e];
+    }
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+      const double tr = (r0 + r < R) ? trow[r] : 0.0;    // uniform across the workgroup
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = fma(tr, w[r][e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) o.e[e] = (T)acc[e];
+    st_stream(reinterpret_cast<VT*>(out + i * P + c), o);
+  }
+}
+
+template <typename T>
+static int run_recon(const double* Tm, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
+                     const double* mean, T* out, hipStream_t st) {
+  if (!Tm || !WA || !WB || !out || I <= 0 || R <= 0 || A <= 0 || B <= 0 || ldt < R) { set_error("recon: bad argument"); return CMTFPLS_EINVAL; }
+  constexpr int V = VecOf<T>::N;
+  if ((B % V) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) {
+    set_error("recon: the last-mode product must be a multiple of 16 bytes and the output 16-byte aligned");
+    return CMTFPLS_EUNSUPPORTED;
+  }
+  const int64_t P = (int64_t)A * B;
+  const int col_tiles = (int)((P / V + kSweepThreads - 1) / kSweepThreads);
+  int64_t want = (2048 + col_tiles - 1) / col_tiles;
+  int64_t rpb = (I + want - 1) / want;
+  if (rpb < 8) rpb = 8;
+  const int row_blocks = (int)((I + rpb - 1) / rpb);
+  const dim3 grid(col_tiles, row_blocks), block(kSweepThreads);
+  for (int r0 = 0; r0 < R; r0 += kReconMaxR) {
+    const int rc = (R - r0 < kReconMaxR) ? R - r0 : kReconMaxR;
+    const int acc = r0 > 0;
+    if (rc <= 4) hipLaunchKernelGGL((recon_kernel<T, 4>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
+    else if (rc <= 8) hipLaunchKernelGGL((recon_kernel<T, 8>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
+    else if (rc <= 12) hipLaunchKernelGGL((recon_kernel<T, 12>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
+    else hipLaunchKernelGGL((recon_kernel<T, 16>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
+  }
+  return check_launch("recon");
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+int cmtfpls_recon_f32(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
+                      const double* mean, float* out, void* stream) {
+  return run_recon<float>(T, I, ldt, R, WA, WB, A, B, mean, out, (hipStream_t)stream);
+}
+int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
+                      const double* mean, double* out, void* stream) {
+  return run_recon<double>(T, I, ldt, R, WA, WB, A, B, mean, out, (hipStream_t)stream);
+}
+}

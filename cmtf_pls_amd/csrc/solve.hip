@@ -1,0 +1,147 @@
+// Tiny dense f64 algebra that used to round-trip through the host between two X sweeps:
+//   normal_solve      : coef_[:, a] = lstsq(T, u)  (tpls.py:110-112) from the (a+1) x (a+1) normal equations
+//   unit_upper_solve  : T (I + triu(G, 1)) = M     (the R x R fix-up of the one-pass projection, engine.project)
+//   kr_gram           : G (.)= L^T L               (Gram of a Khatri-Rao product = Hadamard product of the mode Grams)
+//   khatri_rao        : column-wise Kronecker product of two loading matrices
+// Each is one workgroup (or one thread per row) of plain f64 code: the sizes are R <= 64, launches are
+// latency, and the point is that the component epilogue has no device -> host -> device hop.
+#include "common.hpp"
+
+namespace cmtfpls {
+
+constexpr int kSolveMax = 64;
+
+// Solve G b = g for symmetric positive semi-definite G (k x k, row-major, k <= 64) by a Cholesky
+// factorisation of the EQUILIBRATED matrix D G D, D = diag(G)^(-1/2): the scores' columns differ in scale by
+// orders of magnitude (late components of a well-explained X), which the reference's lstsq on T itself
+// tolerates (rcond = machine precision relative to T's largest singular value); solving the raw normal
+// equations would square that spread.  A column whose pivot falls below k * eps after equilibration is linearly
+// dependent on the earlier ones to working precision (or identically zero): its coefficient is set to 0 and it
+// is dropped from the system, which is what a truncated least-squares solve does with it.
+__global__ __launch_bounds__(kSolveMax) void normal_solve_kernel(const double* __restrict__ G, const double* __restrict__ g, int k,
+                                                                double* __restrict__ b, int incb) {
+  __shared__ double A[kSolveMax][kSolveMax + 1];
+  __shared__ double d[kSolveMax], y[kSolveMax];
+  __shared__ int dep[kSolveMax];
+  const int i = threadIdx.x;
+  if (i < k) {
+    const double gii = G[(int64_t)i * k + i];
+    d[i] = (gii > 0.0 && isfinite(gii)) ? 1.0 / sqrt(gii) : 0.0;
+    dep[i] = 0;
+  }
+  __syncthreads();
+  if (i < k) {
+    for (int j = 0; j < k; ++j) A[i][j] = G[(int64_t)i * k + j] * d[i] * d[j];
+    y[i] = g[i] * d[i];
+  }
+  __syncthreads();
+  const double tiny = (double)k * 2.220446049250313e-16;
+  for (int c = 0; c < k; ++c) {
+    const double piv = A[c][c];
+    const bool ok = piv > tiny;               // uniform: every thread reads the same LDS word
+    __syncthreads();
+    if (ok) {
+      const double l = sqrt(piv);
+      if (i == c) A[c][c] = l;
+      if (i > c && i < k) A[i][c] = A[i][c] / l;
+    } else {
+      if (i == c) { A[c][c] = 1.0; dep[c] = 1; }
+      if (i > c && i < k) A[i][c] = 0.0;
+    }
+    __syncthreads();
+    if (ok && i > c && i < k) {
+      const double lic = A[i][c];
+      for (int j = c + 1; j <= i; ++j) A[i][j] -= lic * A[j][c];
+    }
+    __syncthreads();
+  }
+  // forward L z = y, backward L^T x = z (thread 0: k <= 64, a few hundred dependent flops)
+  if (i == 0) {
+    for (int r = 0; r < k; ++r) {
+      double s = y[r];
+      for (int j = 0; j < r; ++j) s -= A[r][j] * y[j];
+      y[r] = dep[r] ? 0.0 : s / A[r][r];
+    }
+    for (int r = k - 1; r >= 0; --r) {
+      double s = y[r];
+      for (int j = r + 1; j < k; ++j) s -= A[j][r] * y[j];
+      y[r] = dep[r] ? 0.0 : s / A[r][r];
+    }
+  }
+  __syncthreads();
+  if (i < k) b[(int64_t)i * incb] = y[i] * d[i];
+}
+
+// rows of T solve  T (I + triu(U, 1)) = M:  t_a = m_a - sum_{j < a} t_j U[j][a]   (one thread per row, in place)
+__global__ __launch_bounds__(256) void unit_upper_solve_rows_kernel(double* __restrict__ Mx, int64_t I, int ld, int R,
+                                                                   const double* __restrict__ U) {
+  __shared__ double Us[kSolveMax * kSolveMax];
+  for (int idx = threadIdx.x; idx < R * R; idx += 256) Us[idx] = U[idx];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= I) return;
+  double* row = Mx + i * ld;                 // t_j (j < a) is read back from the row this thread just wrote
+#pragma unroll 1
+  for (int a = 0; a < R; ++a) {
+    double s = row[a];
+    for (int j = 0; j < a; ++j) s -= row[j] * Us[j * R + a];
+    row[a] = s;
+  }
+}
+
+// G[r][s] = (first ? 1 : G[r][s]) * scale * sum_j L[j][r] L[j][s]     (L: n x R row-major; one workgroup)
+__global__ __launch_bounds__(256) void kr_gram_kernel(const double* __restrict__ L, int n, int R, double* __restrict__ G,
+                                                     int first, double scale) {
+  for (int o = threadIdx.x; o < R * R; o += 256) {
+    const int r = o / R, s = o % R;
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc = fma(L[(int64_t)j * R + r], L[(int64_t)j * R + s], acc);
+    G[o] = (first ? 1.0 : G[o]) * scale * acc;
+  }
+}
+
+// out[(j * nb + k) * R + r] = Am[j * R + r] * Bm[k * R + r]
+__global__ __launch_bounds__(256) void khatri_rao_kernel(const double* __restrict__ Am, int na, const double* __restrict__ Bm, int nb,
+                                                        int R, double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tot = (int64_t)na * nb * R;
+  if (idx >= tot) return;
+  const int r = (int)(idx % R);
+  const int64_t jk = idx / R;
+  out[idx] = Am[(jk / nb) * R + r] * Bm[(jk % nb) * R + r];
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+
+int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b, int incb, void* stream) {
+  if (!G || !g || !b || k <= 0 || incb <= 0) { set_error("normal_solve: bad argument"); return CMTFPLS_EINVAL; }
+  if (k > kSolveMax) { set_error("normal_solve: more than 64 components"); return CMTFPLS_EUNSUPPORTED; }
+  hipLaunchKernelGGL(normal_solve_kernel, dim3(1), dim3(kSolveMax), 0, (hipStream_t)stream, G, g, k, b, incb);
+  return check_launch("normal_solve");
+}
+
+int cmtfpls_unit_upper_solve_rows_f64(double* Mx, int64_t I, int ld, int R, const double* U, void* stream) {
+  if (!Mx || !U || I <= 0 || R <= 0 || ld < R) { set_error("unit_upper_solve_rows: bad argument"); return CMTFPLS_EINVAL; }
+  if (R > kSolveMax) { set_error("unit_upper_solve_rows: more than 64 components"); return CMTFPLS_EUNSUPPORTED; }
+  hipLaunchKernelGGL(unit_upper_solve_rows_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Mx, I, ld, R, U);
+  return check_launch("unit_upper_solve_rows");
+}
+
+int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, double scale, void* stream) {
+  if (!L || !G || n <= 0 || R <= 0) { set_error("kr_gram: bad argument"); return CMTFPLS_EINVAL; }
+  hipLaunchKernelGGL(kr_gram_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, L, n, R, G, first, scale);
+  return check_launch("kr_gram");
+}
+
+int cmtfpls_khatri_rao_f64(const double* Am, int na, const double* Bm, int nb, int R, double* out, void* stream) {
+  if (!Am || !Bm || !out || na <= 0 || nb <= 0 || R <= 0) { set_error("khatri_rao: bad argument"); return CMTFPLS_EINVAL; }
+  const int64_t tot = (int64_t)na * nb * R;
+  hipLaunchKernelGGL(khatri_rao_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Am, na, Bm, nb, R, out);
+  return check_launch("khatri_rao");
+}
+
+}  // extern "C"

@@ -268,6 +268,112 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_contract_kernel(
   if (threadIdx.x == 0) ssq_part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = sblk;
 }
 
+// The same fused sweep with one 1024-thread WORKGROUP per row segment (<= 1024 * V * 4 elements; one per CU): a
+// lane owns the same 4 column vectors in every row its workgroup visits -- their wA / wB entries and the 16 f64
+// accumulators of Z live in registers -- and two rows are in flight.  This is the access pattern that reaches the
+// read-modify-write ceiling of the chip (6.0 TB/s, tools/exp/rowexp.hip "col-owner 1024thr x4 RU2"; the
+// 256-thread column-tile form above stops at 5.0 TB/s under the register pressure of its 4 x 2 rows in flight).
+// u = Y q is formed up front by the rowdot kernel (one small launch instead of a per-workgroup prologue).
+// One partial row of Z per workgroup (gridDim / nseg partial rows), summed by reduce_rows_kernel in index order.
+template <typename T, int MODE, bool KC>
+__global__ __launch_bounds__(1024) void deflate_contract_rows_kernel(
+    T* __restrict__ X, int64_t I, unsigned P, int B, int nseg, const double* __restrict__ t,
+    const double* __restrict__ wA, const double* __restrict__ wB, const double* __restrict__ u,
+    double* __restrict__ part, double* __restrict__ ssq_part) {
+  __shared__ double red[16];
+  constexpr int V = VecOf<T>::N;
+  constexpr int NV = 4, RU = 2;
+  using VT = Pack<T, V>;
+  constexpr unsigned stride = 1024u * V;
+  const unsigned Pseg = P / (unsigned)nseg;
+  const unsigned seg = blockIdx.x % (unsigned)nseg;
+  const unsigned c0 = threadIdx.x * V;
+  double acc[NV][V], wa[NV], wb[KC ? 1 : NV][V];
+  bool ok[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const unsigned c = c0 + n * stride;
+    ok[n] = c < Pseg;
+    const unsigned cg = seg * Pseg + (ok[n] ? c : 0);
+    wa[n] = wA[cg / (unsigned)B];                          // B % V == 0: one j for the whole vector
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      acc[n][e] = 0.0;
+      if (!KC || n == 0) wb[KC ? 0 : n][e] = wB[cg % (unsigned)B + e];
+    }
+  }
+  double ssq = 0.0;
+  const int64_t step = gridDim.x / nseg;
+  T* __restrict__ xs = X + seg * Pseg + c0;
+  int64_t r = blockIdx.x / nseg;
+  for (; r + (RU - 1) * step < I; r += RU * step) {
+    VT x[RU][NV];
+    double uu[RU], tt[RU];
+#pragma unroll
+    for (int q = 0; q < RU; ++q) {
+      uu[q] = u[r + q * step];
+      tt[q] = t[r + q * step];
+#pragma unroll
+      for (int n = 0; n < NV; ++n)
+        if (ok[n]) x[q][n] = ld_stream(reinterpret_cast<const VT*>(xs + (r + q * step) * (int64_t)P + n * stride));
+    }
+#pragma unroll
+    for (int q = 0; q < RU; ++q)
+#pragma unroll
+      for (int n = 0; n < NV; ++n)
+        if (ok[n]) {
+          const double tw = tt[q] * wa[n];
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const T nv = (T)fma(-tw, wb[KC ? 0 : n][e], (double)x[q][n].e[e]);
+            x[q][n].e[e] = nv;
+            const double d = (nv == nv) ? (double)nv : 0.0;          // NaN (missing) stays NaN, skipped in the norm
+            ssq = fma(d, d, ssq);
+            acc[n][e] = fma((MODE == 0) ? (double)nv : d, uu[q], acc[n][e]);
+          }
+          st_stream(reinterpret_cast<VT*>(xs + (r + q * step) * (int64_t)P + n * stride), x[q][n]);
+        }
+  }
+  for (; r < I; r += step) {
+    const double ur = u[r], tr = t[r];
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+      if (ok[n]) {
+        VT x = ld_stream(reinterpret_cast<const VT*>(xs + r * (int64_t)P + n * stride));
+        const double tw = tr * wa[n];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const T nv = (T)fma(-tw, wb[KC ? 0 : n][e], (double)x.e[e]);
+          x.e[e] = nv;
+          const double d = (nv == nv) ? (double)nv : 0.0;
+          ssq = fma(d, d, ssq);
+          acc[n][e] = fma((MODE == 0) ? (double)nv : d, ur, acc[n][e]);
+        }
+        st_stream(reinterpret_cast<VT*>(xs + r * (int64_t)P + n * stride), x);
+      }
+  }
+  double* __restrict__ prow = part + (int64_t)(blockIdx.x / nseg) * P + seg * Pseg + c0;
+#pragma unroll
+  for (int n = 0; n < NV; ++n)
+    if (ok[n]) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) prow[n * stride + e] = acc[n][e];
+    }
+  const double sblk = block_sum(ssq, red);
+  if (threadIdx.x == 0) ssq_part[blockIdx.x] = sblk;
+}
+
+constexpr int kDcRowsGrid = 256;        // one 1024-thread workgroup per CU
+
+// segments per row for the workgroup-per-row-segment kernels (0: shape outside that form)
+static int rows_nseg(int64_t P, int V, int grid) {
+  if (P <= (int64_t)256 * V * 4 || P >= ((int64_t)1 << 31)) return 0;
+  const int64_t segmax = (int64_t)1024 * V * 4;
+  int nseg = (int)((P + segmax - 1) / segmax);
+  while (nseg <= 64 && ((P % ((int64_t)nseg * V)) != 0 || (grid % nseg) != 0)) ++nseg;
+  return nseg <= 64 ? nseg : 0;
+}
+
 // Narrow blocks (P <= 128 vectors of 16 B, e.g. the I x 512 matrix block of a coupled fit): one row
 // needs only ncv = P / V threads, so the workgroup's 256 threads take RS = 256 / ncv rows at a time
 // (thread = (row lane, column vector)) and the RS row lanes are added in index order through LDS.
@@ -494,6 +600,30 @@ static int run_deflate_contract(T* X, int64_t I, int A, int B, const double* t, 
     set_error("deflate_contract_yq: shape outside the fused form; use deflate, then mode0_contract");
     return CMTFPLS_EUNSUPPORTED;
   }
+#ifndef CMTFPLS_DC_ROWS
+#define CMTFPLS_DC_ROWS 1
+#endif
+  const int nseg = CMTFPLS_DC_ROWS ? rows_nseg(P, Vt, kDcRowsGrid) : 0;
+  if (nseg > 0 && I >= 2 * kDcRowsGrid) {
+    // workgroup-per-row-segment form: partial rows | ssq partials | u = Y q
+    const size_t nrows_part = (size_t)(kDcRowsGrid / nseg);
+    const size_t need_r = (nrows_part * (size_t)P + (size_t)kDcRowsGrid + (size_t)I) * sizeof(double);
+    if (!ws || ws_bytes < need_r) { set_error("deflate_contract_yq: workspace too small"); return CMTFPLS_EWORKSPACE; }
+    double* part = static_cast<double*>(ws);
+    double* sspart = part + nrows_part * (size_t)P;
+    double* u_ws = sspart + kDcRowsGrid;
+    const int rc = cmtfpls_rowdot_f64(Y, ldy, M, I, q, u_ws, nullptr, nullptr, nullptr, 0, st);
+    if (rc != CMTFPLS_OK) return rc;
+    const bool kc = ((1024 * Vt) % B) == 0 && ((P / nseg) % B) == 0;
+    const dim3 g(kDcRowsGrid), b(1024);
+#define DCR(MD, K) hipLaunchKernelGGL((deflate_contract_rows_kernel<T, MD, K>), g, b, 0, st, X, I, (unsigned)P, B, nseg, t, wA, wB, u_ws, part, sspart)
+    if (masked) { if (kc) DCR(1, true); else DCR(1, false); }
+    else        { if (kc) DCR(0, true); else DCR(0, false); }
+#undef DCR
+    launch_reduce_rows(part, (int)nrows_part, P, Z, st);
+    launch_reduce_rows(sspart, kDcRowsGrid, 1, ssq, st);
+    return check_launch("deflate_contract_yq");
+  }
   const size_t nss = (size_t)p.col_tiles * p.row_blocks;
   const bool pre = p.col_tiles >= kYqUnfuseTiles;          // wide block: u = Y q once, up front (see run_contract)
   const size_t need = ((size_t)p.row_blocks * (size_t)P + nss + (pre ? (size_t)I : 0)) * sizeof(double);
@@ -680,7 +810,8 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_kernel(
 // row is read (NV 16-byte loads per lane in flight), updated and written back by the same workgroup, so
 // HBM sees long read bursts followed by long write bursts of the same pages.  Measured against the
 // wavefront-per-row kernel above: 1.57 vs 1.60 ms at 65536 x 128 x 128 f32, 3.15 vs 3.27 ms at
-// 32768 x 256 x 256 (profiles/r01p_tune_sweeps.txt).  Same arithmetic, bit for bit.
+// 32768 x 256 x 256 (profiles/r01p_tune_sweeps.txt); round 2 added the barrier between the two bursts.
+// Same arithmetic, bit for bit.
 template <typename T, int NV, int MAXT, bool KC>
 __global__ __launch_bounds__(MAXT) void deflate_rows_kernel(
     T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ t,
@@ -712,6 +843,9 @@ __global__ __launch_bounds__(MAXT) void deflate_rows_kernel(
       const unsigned c = c0 + n * stride;
       x[n] = ld_stream(reinterpret_cast<const VT*>(xr + ((c < P) ? c : 0)));        // clamped: no branch around the load
     }
+    // every wavefront's loads have landed before any of them stores: the row goes to HBM as one read burst and one
+    // write burst instead of 16 interleaved streams (5.6 -> 5.9 TB/s for this access pattern, tools/exp/rowexp.hip)
+    __syncthreads();
     KronWalk w = w0;
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
@@ -987,11 +1121,101 @@ static int run_deflate(T* X, int64_t I, int A, int B, const double* t, const dou
   return check_launch("deflate");
 }
 
+// Centring with one WORKGROUP per row segment (the layout of deflate_rows_kernel): a lane owns the same NV = 4
+// column vectors in every row it visits, so its means live in registers; the segment is one read burst, the
+// observation count is a workgroup sum (whose barrier separates the bursts) and the segment is one write burst.
+// Rows longer than 1024 * V * 4 elements are cut into nseg segments; workgroup b keeps segment b % nseg (gridDim
+// is a multiple of nseg) and the per-row counts of the segments are added with a f64 atomic -- exact and order
+// independent because they are integers (rowcnt is zeroed by the host first).  Same arithmetic per element as
+// center_kernel.
+template <typename T, int MAXT>
+__global__ __launch_bounds__(MAXT) void center_rows_kernel(
+    T* __restrict__ X, int64_t I, unsigned P, int nseg, const double* __restrict__ mean,
+    double* __restrict__ rowcnt, double* __restrict__ ssq_part) {
+  __shared__ double red[2][16];
+  __shared__ double red2[16];
+  constexpr int V = VecOf<T>::N;
+  constexpr int NV = 4;
+  using VT = Pack<T, V>;
+  constexpr unsigned stride = (unsigned)MAXT * V;
+  const unsigned Pseg = P / (unsigned)nseg;                 // host: P % (nseg * V) == 0
+  const unsigned seg = blockIdx.x % (unsigned)nseg;
+  const unsigned c0 = threadIdx.x * V;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double mu[NV][V];
+#pragma unroll
+  for (int n = 0; n < NV; ++n)
+#pragma unroll
+    for (int e = 0; e < V; ++e) { const unsigned c = c0 + n * stride; mu[n][e] = (c < Pseg) ? mean[seg * Pseg + c + e] : 0.0; }
+  double ssq = 0.0;
+  int parity = 0;
+  for (int64_t row = blockIdx.x / nseg; row < I; row += gridDim.x / nseg, parity ^= 1) {
+    T* __restrict__ xr = X + row * (int64_t)P + seg * Pseg;
+    VT x[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const unsigned c = c0 + n * stride;
+      x[n] = ld_stream(reinterpret_cast<const VT*>(xr + ((c < Pseg) ? c : 0)));     // clamped: no branch around the load
+    }
+    double cnt = 0.0;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const unsigned c = c0 + n * stride;
+      if (c < Pseg) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const T nv = (T)((double)x[n].e[e] - mu[n][e]);
+          x[n].e[e] = nv;
+          const bool obs = (nv == nv);
+          cnt += obs ? 1.0 : 0.0;
+          const double d = obs ? (double)nv : 0.0;
+          ssq = fma(d, d, ssq);
+        }
+      }
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) red[parity][wv] = cnt;
+    __syncthreads();                                     // also: every load has landed before the first store
+    if (rowcnt && threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < MAXT / 64; ++w) tot += red[parity][w];
+      if (nseg == 1) rowcnt[row] = tot;
+      else atomicAdd(rowcnt + row, tot);
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const unsigned c = c0 + n * stride;
+      if (c < Pseg) st_stream(reinterpret_cast<VT*>(xr + c), x[n]);
+    }
+  }
+  if (ssq_part) {
+    const double sblk = block_sum(ssq, red2);
+    if (threadIdx.x == 0) ssq_part[blockIdx.x] = sblk;
+  }
+}
+
 template <typename T>
 static int run_center(T* X, int64_t I, int64_t P, const double* mean, double* rowcnt, double* ssq_part, hipStream_t st) {
   if (!X || !mean || I <= 0 || P <= 0) { set_error("center: bad argument"); return CMTFPLS_EINVAL; }
   const dim3 g(kSweepBlocks), b(kSweepThreads);
   const bool v = (P % VecOf<T>::N == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  constexpr int Vc = VecOf<T>::N;
+  // rows of more than 256 * V * 4 elements: one workgroup per row segment of <= 1024 * V * 4 elements (read burst,
+  // barrier, write burst); > half of the LDS as dynamic padding keeps it at ONE segment per CU, as for
+  // deflate_rows_kernel
+  if (v && P > (int64_t)256 * Vc * 4 && P < ((int64_t)1 << 31)) {
+    const int64_t segmax = (int64_t)1024 * Vc * 4;
+    int nseg = (int)((P + segmax - 1) / segmax);
+    while (nseg <= 64 && ((P % ((int64_t)nseg * Vc)) != 0 || (kSweepBlocks % nseg) != 0)) ++nseg;
+    if (nseg <= 64) {
+      if (nseg > 1 && rowcnt) {
+        const hipError_t e = hipMemsetAsync(rowcnt, 0, (size_t)I * sizeof(double), st);
+        if (e != hipSuccess) { set_error("center: memset failed"); return CMTFPLS_EHIP; }
+      }
+      hipLaunchKernelGGL((center_rows_kernel<T, 1024>), g, dim3(1024), 81920, st, X, I, (unsigned)P, nseg, mean, rowcnt, ssq_part);
+      return check_launch("center");
+    }
+  }
   if (v) hipLaunchKernelGGL((center_kernel<T, true>), g, b, 0, st, X, I, P, mean, rowcnt, ssq_part);
   else hipLaunchKernelGGL((center_kernel<T, false>), g, b, 0, st, X, I, P, mean, rowcnt, ssq_part);
   return check_launch("center");
@@ -1085,7 +1309,10 @@ size_t cmtfpls_deflate_contract_workspace_bytes(int64_t I, int64_t P) {
   if (I <= 0 || P <= 0) return 0;
   const ContractPlan a = plan_contract(I, P, 4), b = plan_contract(I, P, 8);
   const size_t na = (size_t)a.row_blocks * ((size_t)P + a.col_tiles), nb = (size_t)b.row_blocks * ((size_t)P + b.col_tiles);
-  return ((na > nb ? na : nb) + (size_t)I) * sizeof(double);   // + u = Y q of the wide-block form
+  const size_t colform = ((na > nb ? na : nb) + (size_t)I) * sizeof(double);   // + u = Y q of the wide-block form
+  // workgroup-per-row-segment form: at most kDcRowsGrid partial rows of P doubles, the ssq partials, u = Y q
+  const size_t rowform = ((size_t)kDcRowsGrid * (size_t)P + (size_t)kDcRowsGrid + (size_t)I) * sizeof(double);
+  return colform > rowform ? colform : rowform;
 }
 int cmtfpls_deflate_contract_yq_f32(float* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB,
                                     const double* Y, int ldy, int M, const double* q, double* Z, int masked, double* ssq,

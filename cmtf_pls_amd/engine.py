@@ -82,6 +82,7 @@ class BlockState:
     colcnt: Optional[torch.Tensor]   # (P,) global observation counts (masked blocks)
     rowcnt: Optional[torch.Tensor]   # (I_local,)
     ssq0: float
+    dtype: Optional[torch.dtype] = None                                           # storage type of the block on the GPU
     loadings: List[torch.Tensor] = field(default_factory=list)   # per trailing mode: (dim, R) f64
     r2x: Optional[np.ndarray] = None
 
@@ -131,7 +132,7 @@ class NipalsEngine:
         rowcnt, ssq0 = be.center(X2, mean, has_miss)
         comm.allreduce(ssq0)
         return BlockState(shape=tuple(X.shape), A=A, B=B, mean=mean, has_miss=has_miss,
-                          colcnt=colcnt if has_miss else None, rowcnt=rowcnt, ssq0=float(ssq0.item()))
+                          colcnt=colcnt if has_miss else None, rowcnt=rowcnt, ssq0=float(ssq0.item()), dtype=X.dtype)
 
     def _rank1(self, blk: BlockState, Z: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
                info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None,
@@ -240,6 +241,31 @@ class NipalsEngine:
             scores[:, a].copy_(t)
         return scores
 
+    def reconstruct(self, state: FitState, block: int = 0, rows: Optional[slice] = None) -> Optional[torch.Tensor]:
+        """Rows of factors_to_tensor(X_factors) + X_mean (util.py:18-20 with tpls.py:188-189 / cmtf.py:233-237) for
+        one block, formed on the GPU in the block's storage type: Xhat = T (W_1 (.) W_2 (.) ...)^T + mean with the
+        Khatri-Rao operand never materialised (cmtfpls_recon_*).  None when the backend / shape has no device form
+        (the caller falls back to the host einsum)."""
+        be = self.be
+        if not hasattr(be, "recon"):
+            return None
+        blk = state.blocks[block]
+        with self.device_ctx():
+            T = state.T if rows is None else state.T[rows]
+            R = state.n_components
+            loads = blk.loadings
+            if len(blk.shape) == 2:
+                WA, WB = be.empty(1, R), loads[0]
+                WA.fill_(1.0)
+            else:
+                WA, WB = loads[0], loads[1]
+                for L in loads[2:]:
+                    WB = be.khatri_rao(WB, L)
+            out = be.empty(T.shape[0], blk.A * blk.B, dtype=blk.dtype or torch.float64)
+            if T.shape[0] == 0 or be.recon(T, WA, WB, blk.mean, out) is None:
+                return None
+            return out.view((T.shape[0],) + tuple(blk.shape[1:]))
+
     def _project_one_pass(self, state: FitState, Xs: List[torch.Tensor], mixed: bool = False) -> Optional[torch.Tensor]:
         """All R scores from ONE read of every (already centred, NaN-free) block.
 
@@ -252,27 +278,26 @@ class NipalsEngine:
         R = state.n_components
         I = Xs[0].shape[0]
         nb = len(Xs)
+        if R > 64:
+            return None
         Ms = be.empty(nb, I * R)
-        Gbar = np.zeros((R, R))
+        Gs = be.empty(nb, R * R)
         for b, (blk, X) in enumerate(zip(state.blocks, Xs)):
-            loads = [L.cpu().numpy() for L in blk.loadings]
+            loads = blk.loadings
             if len(blk.shape) == 2:
-                WA_h, WB_h = np.ones((1, R)), loads[0]
+                WA, WB = be.empty(1, R), loads[0]
+                WA.fill_(1.0)
             else:
-                WA_h = loads[0]
-                WB_h = loads[1]
+                WA, WB = loads[0], loads[1]
                 for L in loads[2:]:                       # column-wise Kronecker of the remaining modes
-                    WB_h = (WB_h[:, None, :] * L[None, :, :]).reshape(-1, R)
-            WA = torch.from_numpy(np.ascontiguousarray(WA_h)).to(X.device)
-            WB = torch.from_numpy(np.ascontiguousarray(WB_h)).to(X.device)
+                    WB = be.khatri_rao(WB, L)
             if be.mttkrp(X.view(I, -1), blk.A, blk.B, WA, WB, Ms[b].view(I, R), mixed=mixed) is None:
                 return None
-            Gbar += (WA_h.T @ WA_h) * (WB_h.T @ WB_h)
-        Gbar /= nb
+            for m, L in enumerate(loads):                 # Gram of a Khatri-Rao product = Hadamard product of the mode Grams
+                be.kr_gram(L, Gs[b], first=(m == 0))
         Mbar = be.scores_mean(Ms, be.empty(I * R)).view(I, R) if nb > 1 else Ms[0].view(I, R)
-        tri = np.eye(R) + np.triu(Gbar, 1)
-        T = np.linalg.solve(tri.T, Mbar.cpu().numpy().T).T      # T (I + U) = M
-        return torch.from_numpy(np.ascontiguousarray(T))
+        Gbar = be.scores_mean(Gs, be.empty(R * R)).view(R, R) if nb > 1 else Gs[0].view(R, R)
+        return be.unit_upper_solve_rows(Mbar, Gbar)             # T (I + triu(Gbar, 1)) = Mbar, on the device
 
 
 class FitRun:
@@ -306,7 +331,12 @@ class FitRun:
         self.T = be.zeros(I, R)
         self.U = be.zeros(I, R)
         self.Q = be.zeros(M, R)
-        self.coef = np.zeros((R, R))
+        self.coef = np.zeros((R, R))                              # filled from coef_dev by result()
+        self.coef_dev = be.zeros(R, R)
+        self.b_dev = be.empty(R)
+        # per component: local sums of squares of every deflated block and of the deflated Y (the R2X / R2Y
+        # numerators, tpls.py:115-120); all-reduced and read back ONCE, in result()
+        self.ssq_log = be.zeros(R, len(self.blocks) + 1)
         self.r2y = np.zeros(R)
         for blk in self.blocks:
             blk.loadings = [be.zeros(d, R) for d in blk.shape[1:]]
@@ -345,7 +375,6 @@ class FitRun:
         # dq^T (Y^T Y) dq.  More responses keep the separate gram_tn / normalize / rowdot launches.
         # Coupled blocks: normalize(Y^T mean_b t_b) = normalize(sum_b Y^T t_b), so every block's score kernel
         # adds its partial rows and the averaged score itself is only formed once per component.
-        self._pending = None                      # (component, [ssq per block..., ssq of Y]) still on the device
         self._z_ready = False                     # Zs already hold X x_0 u_0 of the component about to start
         self._fused = (algorithm == "direct" and M <= 64
                        and all(hasattr(be, f) for f in ("mode0_contract_yq", "score_gram", "q_update")))
@@ -467,11 +496,12 @@ class FitRun:
                 self.sq_budget[b] = self.sq_max
                 retry = True
             elif conv and len(self.blocks[b].shape) == 3:
-                # convergence is seen by launch used + 1; keep one spare.  Under graph replay the launch sequence
-                # is part of the captured graph: hysteresis (re-plan only outside [used+1, used+4]) keeps it stable;
-                # eager launches follow the need exactly (every spare launch is 4.5 us of an idle GPU)
-                if not self.use_graphs or used + 1 > self.sq_budget[b] or used + 4 < self.sq_budget[b]:
-                    self.sq_budget[b] = min(self.sq_max, used + 2)
+                # the last computing launch (`used`) declares its own output final, or launch used + 1 sees it; keep
+                # one spare.  Under graph replay the launch sequence is part of the captured graph: hysteresis
+                # (re-plan only outside [used+1, used+3]) keeps it stable; eager launches follow the need exactly
+                # (every spare launch is ~4 us of an idle GPU)
+                if not self.use_graphs or used + 1 > self.sq_budget[b] or used + 3 < self.sq_budget[b]:
+                    self.sq_budget[b] = min(self.sq_max, used + 1)
         return retry
 
     def _read_status(self) -> np.ndarray:
@@ -704,45 +734,39 @@ class FitRun:
             self._finish_fused(a)
             return
         # inner regression: coef_[:, a] = lstsq(T, u) with columns > a still zero (tpls.py:110-112)
-        Ta = self.T[:, : a + 1]
+        b_dev, _ = self._inner_regression(a)
+        for b in range(len(self.blocks)):
+            self.ssq_log[a, b].copy_(ssqs[b].reshape(()))                        # tpls.py:115-117 (booked in result())
+        ssqy = be.y_deflate(self.Y, self.T, a + 1, b_dev, self.q)                # tpls.py:113
+        self.ssq_log[a, len(self.blocks)].copy_(ssqy.reshape(()))                # tpls.py:118-120
+
+    def _inner_regression(self, a: int, extra: Optional[torch.Tensor] = None):
+        """b = lstsq(T[:, :a+1], u) (tpls.py:110-112) from the normal equations, entirely on the device: Gram
+        and right-hand side (all-reduced when sharded, together with `extra`), equilibrated Cholesky in one
+        workgroup; the coefficients go into column a of the device coef matrix.  Returns (b, reduced extra)."""
+        be, comm = self.eng.be, self.eng.comm
+        k = a + 1
+        Ta = self.T[:, :k]
         G = be.gram_tn(Ta, Ta)
         g = be.gram_tn(Ta, self.u)
-        packed = torch.cat([G.reshape(-1), g.reshape(-1)] + [s.reshape(-1) for s in ssqs])
-        comm.allreduce(packed)
-        host = packed.cpu().numpy()
-        k = a + 1
-        Gh, gh = host[: k * k].reshape(k, k), host[k * k: k * k + k]
-        bh = np.linalg.lstsq(Gh, gh, rcond=None)[0]
-        self.coef[:k, a] = bh
-        for b, blk in enumerate(self.blocks):
-            blk.r2x[a] = 1.0 - host[k * k + k + b] / blk.ssq0                    # tpls.py:115-117
-        b_dev = torch.from_numpy(np.ascontiguousarray(bh)).to(self.Y.device)
-        ssqy = be.y_deflate(self.Y, self.T, k, b_dev, self.q)                    # tpls.py:113
-        comm.allreduce(ssqy)
-        self.r2y[a] = 1.0 - float(ssqy.item()) / self.ssqy0                      # tpls.py:118-120
+        if comm.sharded:
+            packed = torch.cat([G.reshape(-1), g.reshape(-1)] + ([extra.reshape(-1)] if extra is not None else []))
+            comm.allreduce(packed)
+            G, g = packed[: k * k].view(k, k), packed[k * k: k * k + k]
+            extra = packed[k * k + k:] if extra is not None else None
+        b_dev = be.normal_solve(G, g.reshape(-1), out=self.b_dev[:k])
+        self.coef_dev[:k, a].copy_(b_dev)
+        return b_dev, extra
 
     def _finish_fused(self, a: int) -> None:
         """Tail of finish_component on the fused direct path.  The inner regression and the Y deflation
         (tpls.py:110-113) depend only on T and u, so they run BEFORE the X deflation (tpls.py:109); the X
         deflation can then be fused with the first contraction of component a+1 (u_0 = Y_new[:, 0] is known):
         one X read less per component.  The deflated norms behind R2X / R2Y (tpls.py:115-120) stay on the
-        device and ride in the NEXT component's packed read-back (or in result()), so a component costs one
-        host synchronisation here instead of two."""
+        device (ssq_log) and are read back once, in result(): a component's epilogue has no host round trip."""
         be, comm = self.eng.be, self.eng.comm
         k = a + 1
-        Ta = self.T[:, :k]
-        G = be.gram_tn(Ta, Ta)
-        g = be.gram_tn(Ta, self.u)
-        pend = self._pending
-        packed = torch.cat([G.reshape(-1), g.reshape(-1)] + ([s.reshape(-1) for s in pend[1]] if pend else []))
-        comm.allreduce(packed)
-        host = packed.cpu().numpy()
-        Gh, gh = host[: k * k].reshape(k, k), host[k * k: k * k + k]
-        bh = np.linalg.lstsq(Gh, gh, rcond=None)[0]                              # tpls.py:110-112
-        self.coef[:k, a] = bh
-        if pend:
-            self._book_r2(pend[0], host[k * k + k:])
-        b_dev = torch.from_numpy(np.ascontiguousarray(bh)).to(self.Y.device)
+        b_dev, _ = self._inner_regression(a)                                     # tpls.py:110-112
         ssqy = be.y_deflate(self.Y, self.T, k, b_dev, self.q)                    # tpls.py:113
         ssqs = []
         self._z_ready = False
@@ -763,7 +787,12 @@ class FitRun:
         else:
             for b, blk in enumerate(self.blocks):
                 ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
-        self._pending = (a, ssqs + [ssqy])
+        self._log_ssq(a, ssqs, ssqy)
+
+    def _log_ssq(self, a: int, ssqs, ssqy) -> None:
+        for b in range(len(self.blocks)):
+            self.ssq_log[a, b].copy_(ssqs[b].reshape(()))                        # tpls.py:115-117 (booked in result())
+        self.ssq_log[a, len(self.blocks)].copy_(ssqy.reshape(()))                # tpls.py:118-120
 
     def _store_component(self, a: int) -> None:
         self.T[:, a].copy_(self.t)
@@ -783,7 +812,7 @@ class FitRun:
         """finish_component of the xcov algorithm when S is carried across the deflation.  Passes over X:
         the final score (read; tpls.py:92-99 with the converged loadings) and the deflation (read + write;
         tpls.py:109), which also forms v = X+^T yhat for the down-date of S -- no S build on the matrix
-        cores for the next component.  R2 bookkeeping is deferred as in _finish_fused."""
+        cores for the next component.  R2 bookkeeping is deferred to result() as in _finish_fused."""
         be, comm = self.eng.be, self.eng.comm
         self.q = self.qc
         for b, blk in enumerate(self.blocks):
@@ -794,21 +823,8 @@ class FitRun:
         self._store_component(a)
         k = a + 1
         Ta = self.T[:, :k]
-        G = be.gram_tn(Ta, Ta)
-        g = be.gram_tn(Ta, self.u)
         ya = be.gram_tn(self.Y, self.t).reshape(-1)                              # Y^T t with the not yet deflated Y
-        pend = self._pending
-        packed = torch.cat([G.reshape(-1), g.reshape(-1), ya] + ([s.reshape(-1) for s in pend[1]] if pend else []))
-        comm.allreduce(packed)
-        host = packed.cpu().numpy()
-        M = self.M
-        Gh, gh = host[: k * k].reshape(k, k), host[k * k: k * k + k]
-        bh = np.linalg.lstsq(Gh, gh, rcond=None)[0]                              # tpls.py:110-112
-        self.coef[:k, a] = bh
-        if pend:
-            self._book_r2(pend[0], host[k * k + k + M:])
-        b_dev = torch.from_numpy(np.ascontiguousarray(bh)).to(self.Y.device)
-        ya_g = packed[k * k + k: k * k + k + M]                                  # all-reduced Y^T t
+        b_dev, ya_g = self._inner_regression(a, extra=ya)                        # tpls.py:110-112; ya_g: all-reduced Y^T t
         ssqs = []
         if k < self.R:
             be.rowdot(Ta, b_dev, self.yhat.view(-1), None)                       # yhat = T b (what Y is deflated by)
@@ -830,23 +846,21 @@ class FitRun:
         else:
             for b, blk in enumerate(self.blocks):
                 ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
-        self._pending = (a, ssqs + [ssqy])
-
-    def _book_r2(self, a: int, vals) -> None:
-        for b, blk in enumerate(self.blocks):
-            blk.r2x[a] = 1.0 - float(vals[b]) / blk.ssq0                         # tpls.py:115-117
-        self.r2y[a] = 1.0 - float(vals[len(self.blocks)]) / self.ssqy0           # tpls.py:118-120
-
-    def _flush_pending(self) -> None:
-        if self._pending:
-            a, tens = self._pending
-            packed = torch.cat([s.reshape(-1) for s in tens])
-            self.eng.comm.allreduce(packed)
-            self._book_r2(a, packed.cpu().numpy())
-            self._pending = None
+        self._log_ssq(a, ssqs, ssqy)
 
     def result(self) -> FitState:
-        self._flush_pending()
+        """The only device -> host traffic of the component epilogues: the R x R coefficients and the
+        R x (blocks + 1) deflated norms, all-reduced once, in one copy."""
+        nb = len(self.blocks)
+        self.eng.comm.allreduce(self.ssq_log)
+        host = torch.cat([self.coef_dev.reshape(-1), self.ssq_log.reshape(-1)]).cpu().numpy()
+        R = self.R
+        self.coef[...] = host[: R * R].reshape(R, R)
+        ssq = host[R * R:].reshape(R, nb + 1)
+        for a in range(len(self.n_iter)):
+            for b, blk in enumerate(self.blocks):
+                blk.r2x[a] = 1.0 - ssq[a, b] / blk.ssq0                          # tpls.py:115-117
+            self.r2y[a] = 1.0 - ssq[a, nb] / self.ssqy0                          # tpls.py:118-120
         return FitState(coupled=self.coupled, n_components=self.R, blocks=self.blocks, T=self.T, U=self.U, Q=self.Q,
                         coef=self.coef, r2y=self.r2y, y_mean=self.y_mean, n_iter=self.n_iter,
                         n_samples_total=self.n_total)

@@ -84,6 +84,18 @@ class _EstimatorBase(Mapping):
     def copy(self):
         return copy(self)
 
+    def _reconstruct(self, block: int, factors, mean, rows=None, device: bool = False):
+        """factors_to_tensor(factors) + mean (tpls.py:188-189, cmtf.py:233-237) through the GPU kernel; `rows` (a
+        slice) restricts it to a row block and `device=True` returns the device tensor in the storage type instead
+        of a float64 NumPy array -- at 65536 x 128 x 128 the reference's host form is an 8.6 GB float64 einsum."""
+        rec = self._get_engine().reconstruct(self._state, block, rows)
+        if rec is None:                                                    # no device form for this shape / backend
+            from .util import factors_to_tensor
+            f = [factors[0] if rows is None else factors[0][rows]] + list(factors[1:])
+            out = factors_to_tensor(f) + mean
+            return torch.from_numpy(out) if device else out
+        return rec if device else rec.cpu().numpy().astype(np.float64)
+
     # shared Y-side epilogue of transform (tpls.py:167-184, cmtf.py:212-229) -- host NumPy, I' x M only
     def _y_scores(self, X_scores: np.ndarray, Y) -> np.ndarray:
         Y = np.array(Y, dtype=float, copy=True)
@@ -119,7 +131,10 @@ class tPLS(_EstimatorBase):
         assert Y.ndim <= 2, "Only a matrix (2-mode tensor) Y is acceptable."
         eng = self._get_engine()
         dev = eng.be.device
-        self.original_X, self.original_Y = X, Y
+        # kept BY REFERENCE (not copied: X may be tens of GB) for validate.get_q2y (validate.py:18-21) and the lazy
+        # X_miss; with copy_X=False the fit centres and deflates the caller's tensor in place, so nothing usable is
+        # left to keep and get_q2y's assertion fires
+        self.original_X, self.original_Y = (X, Y) if self._copy_X else (None, None)
         Y2 = Y.reshape(-1, 1) if Y.ndim == 1 else Y
         self.X_dim = X.ndim
         self.X_shape = tuple(X.shape)
@@ -148,7 +163,7 @@ class tPLS(_EstimatorBase):
     def X_miss(self):
         """Positions of missing values (tpls.py:64); computed lazily: at 65536x128x128 it is a 1 GB array
         nothing on the fit path needs (the kernels read the NaNs in band)."""
-        if self._X_miss is None and isinstance(self.original_X, np.ndarray):
+        if self._X_miss is None and isinstance(self.original_X, np.ndarray):      # (None after copy_X=False)
             self._X_miss = np.isnan(self.original_X)
         return self._X_miss
 
@@ -168,7 +183,5 @@ class tPLS(_EstimatorBase):
             return X_scores, self._y_scores(X_scores, Y)
         return X_scores
 
-    def X_reconstructed(self):
-        from .util import factors_to_tensor
-
-        return factors_to_tensor(self.X_factors) + self.X_mean                          # tpls.py:188-189
+    def X_reconstructed(self, rows=None, device: bool = False):
+        return self._reconstruct(0, self.X_factors, self.X_mean, rows, device)          # tpls.py:188-189

@@ -226,6 +226,30 @@ int cmtfpls_y_deflate_f64(double* Y, int ldy, int M, int64_t I, const double* T,
                           void* stream);
 int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
 
+/* ---- K7 / K8 / projection fix-up without a host round trip ------------------------------------------
+ * normal_solve: b (k entries, stride incb) = argmin |T b - u| from the k x k normal equations G b = g with
+ *   G = T^T T, g = T^T u (row-major f64, k <= 64): `np.linalg.lstsq(T, u, rcond=-1)[0]` of tpls.py:110-112 /
+ *   cmtf.py:135-137 restricted to the k = a + 1 non-zero score columns.  Cholesky of the equilibrated matrix
+ *   diag(G)^(-1/2) G diag(G)^(-1/2) (the score columns differ in scale by orders of magnitude; the raw normal
+ *   equations would square that spread); a column that is zero or dependent to working precision gets b = 0.
+ * unit_upper_solve_rows: rows of M (I x R, leading dim ld) are overwritten by the rows of T solving
+ *   T (I + triu(U, 1)) = M: the R x R part of the one-pass transform / predict (see cmtfpls_mttkrp_*).
+ * kr_gram: G (R x R) = (first ? 1 : G) .* scale * L^T L for one loading matrix L (n x R row-major): the Gram
+ *   matrix of a Khatri-Rao product is the Hadamard product of the mode Grams; call once per mode.
+ * khatri_rao: out ((na * nb) x R) = column-wise Kronecker product of Am (na x R) and Bm (nb x R)
+ *   (tensorly.tenalg.khatri_rao as used by util.py:19, first matrix varying slowest).
+ * recon: Xhat[i, c] = sum_r T[i*ldt + r] * WA[(c / B)*R + r] * WB[(c % B)*R + r] + mean[c]  for I rows, written
+ *   in the storage type: factors_to_tensor (util.py:18-20) + X_mean as X_reconstructed uses it (tpls.py:188-189,
+ *   cmtf.py:233-237), the Khatri-Rao operand never materialised; mean nullable.  B % (16/sizeof(T)) == 0. */
+int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b, int incb, void* stream);
+int cmtfpls_unit_upper_solve_rows_f64(double* M, int64_t I, int ld, int R, const double* U, void* stream);
+int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, double scale, void* stream);
+int cmtfpls_khatri_rao_f64(const double* Am, int na, const double* Bm, int nb, int R, double* out, void* stream);
+int cmtfpls_recon_f32(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
+                      const double* mean, float* out, void* stream);
+int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
+                      const double* mean, double* out, void* stream);
+
 /* ---- measured HBM ceilings (the roofline denominator "re-measured with a device copy
  * kernel"; not a reference call site) ---------------------------------------------------------------
  * Plain 16-byte-per-lane non-temporal streaming kernels over `bytes` of a 16-byte-aligned buffer:

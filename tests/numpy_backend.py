@@ -185,6 +185,34 @@ class NumpyBackend:
         u_out.copy_(u)
         return du2 if u_old is not None else None
 
+    def normal_solve(self, G, g, out=None):
+        Gh, gh = _np(G), _np(g).reshape(-1)
+        d = np.where(np.diag(Gh) > 0, 1.0 / np.sqrt(np.where(np.diag(Gh) > 0, np.diag(Gh), 1.0)), 0.0)
+        z = np.linalg.lstsq(Gh * d[:, None] * d[None, :], gh * d, rcond=None)[0]
+        b = torch.from_numpy(np.ascontiguousarray(z * d))
+        if out is not None:
+            out.copy_(b)
+            return out
+        return b
+
+    def unit_upper_solve_rows(self, M, U):
+        R = M.shape[1]
+        tri = np.eye(R) + np.triu(_np(U), 1)
+        M.copy_(torch.from_numpy(np.ascontiguousarray(np.linalg.solve(tri.T, _np(M).T).T)))
+        return M
+
+    def kr_gram(self, L, G, first):
+        g = torch.from_numpy(_np(L).T @ _np(L)).reshape(G.shape)
+        if first:
+            G.copy_(g)
+        else:
+            G.mul_(g)
+        return G
+
+    def khatri_rao(self, Am, Bm):
+        R = Am.shape[1]
+        return torch.from_numpy(np.ascontiguousarray((_np(Am)[:, None, :] * _np(Bm)[None, :, :]).reshape(-1, R)))
+
     def scores_mean(self, Ts, out):
         out.copy_(torch.from_numpy(np.average(_np(Ts), axis=0)))
         return out

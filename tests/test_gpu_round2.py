@@ -90,3 +90,141 @@ def test_ceiling_kernels_move_the_bytes():
         assert torch.equal(a, torch.arange(n, dtype=torch.float32, device="cuda:0"))
         be.ceiling("read", a, rb, 512)
     torch.cuda.synchronize()
+
+
+# ---- component epilogue / projection / reconstruction on the device (VERDICT r1 #8, #9) ----------------
+@pytest.fixture(scope="module")
+def be():
+    from cmtf_pls_amd.backend import HipBackend
+    return HipBackend("cuda:0")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("k", [1, 3, 10, 33, 64])
+def test_normal_solve_matches_lstsq_on_badly_scaled_scores(be, k):
+    """lstsq(T, u, rcond=-1) (tpls.py:110-112) through the equilibrated normal equations: score columns spread
+    over 12 orders of magnitude (late components of a well-explained X) keep their coefficients."""
+    rng = np.random.default_rng(k)
+    T = rng.normal(size=(500, k)) * np.logspace(0, -12, k)[None, :]
+    T[:, 1:] += 0.3 * T[:, :1] * np.logspace(0, -12, k)[None, 1:]          # not orthogonal
+    u = rng.normal(size=500)
+    want = np.linalg.lstsq(T, u, rcond=-1)[0]
+    got = be.normal_solve(_dev(T.T @ T), _dev(T.T @ u)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+
+
+def test_normal_solve_drops_zero_and_dependent_columns(be):
+    rng = np.random.default_rng(3)
+    T = rng.normal(size=(200, 5))
+    T[:, 2] = 0.0                                  # an all-zero score column
+    T[:, 4] = 2.0 * T[:, 1]                        # an exactly dependent one
+    u = rng.normal(size=200)
+    got = be.normal_solve(_dev(T.T @ T), _dev(T.T @ u)).cpu().numpy()
+    assert got[2] == 0.0 and got[4] == 0.0 and np.all(np.isfinite(got))
+    keep = [0, 1, 3]
+    np.testing.assert_allclose(got[keep], np.linalg.lstsq(T[:, keep], u, rcond=None)[0], rtol=1e-10)
+
+
+def test_projection_fixup_kernels(be):
+    rng = np.random.default_rng(8)
+    I, R = 1000, 7
+    M = rng.normal(size=(I, R))
+    U = rng.normal(size=(R, R))
+    want = np.linalg.solve((np.eye(R) + np.triu(U, 1)).T, M.T).T
+    got = be.unit_upper_solve_rows(_dev(M), _dev(U)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    LA, LB = rng.normal(size=(9, R)), rng.normal(size=(6, R))
+    G = torch.empty(R * R, dtype=torch.float64, device="cuda:0")
+    be.kr_gram(_dev(LA), G, True)
+    be.kr_gram(_dev(LB), G, False)
+    np.testing.assert_allclose(G.cpu().numpy().reshape(R, R), (LA.T @ LA) * (LB.T @ LB), rtol=1e-13)
+    KR = (LA[:, None, :] * LB[None, :, :]).reshape(-1, R)
+    np.testing.assert_array_equal(be.khatri_rao(_dev(LA), _dev(LB)).cpu().numpy(), KR)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("shape,R", [((40, 12, 16), 3), ((33, 20), 4), ((17, 6, 4, 8), 2), ((25, 8, 8), 19)])
+def test_reconstruction_on_device_matches_oracle(shape, R, dtype):
+    """X_reconstructed (tpls.py:188-189) = factors_to_tensor (util.py:18-20) + X_mean through cmtfpls_recon_*."""
+    from cmtf_pls_amd import tPLS
+    x, y, _ = O.import_synthetic(shape, 3, 3, error=0.2, seed=9)
+    if dtype == "float32":
+        x, y = x.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64)
+    m = tPLS(R, dtype=dtype)
+    m.fit(x, y, max_iter=30)
+    rec = m.X_reconstructed()
+    lit = O.cp_factors_to_tensor(m.X_factors) + m.X_mean                 # the literal reference formula on the fitted factors
+    tol = 1e-12 if dtype == "float64" else 2e-7
+    np.testing.assert_allclose(rec, lit, rtol=tol, atol=tol * np.abs(lit).max())
+    assert rec.dtype == np.float64 and rec.shape == x.shape
+    part = m.X_reconstructed(rows=slice(5, 11), device=True)
+    assert part.is_cuda and tuple(part.shape) == (6,) + shape[1:]
+    np.testing.assert_allclose(part.cpu().numpy().astype(np.float64), rec[5:11], rtol=0, atol=0)
+
+
+def test_more_components_than_latent_factors_noise_free():
+    """ADVICE r1: R above the effective rank on noise-free data.  The reference's lstsq(T, u, rcond=-1) keeps the
+    coefficients of tiny score columns; the meaningful components must agree with the oracle and nothing may be
+    truncated to an all-zero coefficient column."""
+    from cmtf_pls_amd import tPLS
+    x, y, _ = O.import_synthetic((60, 7, 5), 3, 2, error=0.0, seed=12)
+    m = tPLS(4)
+    m.fit(x, y, max_iter=50)
+    fit = O.fit_tpls(x, y, 4, max_iter=50)
+    np.testing.assert_allclose(m.coef_[:2, :2], fit.coef[:2, :2], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.R2Y[:2], fit.r2y[:2], rtol=1e-8)
+    np.testing.assert_allclose(m.X_factors[0][:, :2], fit.T[:, :2], rtol=1e-6, atol=1e-8 * np.abs(fit.T).max())
+    assert np.all(np.isfinite(m.coef_)) and np.all(np.diag(m.coef_) != 0.0)
+    assert m.R2Y[-1] > 1 - 1e-10 and fit.r2y[-1] > 1 - 1e-10
+
+
+def test_fit_epilogue_has_no_host_round_trip():
+    """Between start_component and result() the engine reads back ONE status word per iteration through its pinned
+    mirror and nothing else: no .cpu(), no .item(), no .tolist() (VERDICT r1 #8)."""
+    from cmtf_pls_amd.backend import HipBackend
+    from cmtf_pls_amd.engine import NipalsEngine
+    x, y, _ = O.import_synthetic((256, 16, 12), 4, 3, error=0.1, seed=2)
+    for algorithm in ("direct", "xcov"):
+        eng = NipalsEngine(HipBackend("cuda:0"))
+        run = eng.begin([_dev(x)], _dev(y), 3, coupled=False, algorithm=algorithm)
+        calls = []
+        orig = {n: getattr(torch.Tensor, n) for n in ("cpu", "item", "tolist", "numpy")}
+
+        def spy(name):
+            def f(self, *a, **k):
+                if self.is_cuda:
+                    calls.append(name)
+                return orig[name](self, *a, **k)
+            return f
+        try:
+            for n in orig:
+                setattr(torch.Tensor, n, spy(n))
+            for a in range(3):
+                run.start_component(a)
+                for it in range(30):
+                    du = run.iterate(it)
+                    if du is not None and du < 1e-8:
+                        break
+                run.finish_component(a)
+        finally:
+            for n, f in orig.items():
+                setattr(torch.Tensor, n, f)
+        assert calls == [], calls
+        st = run.result()
+        fit = O.fit_tpls(x, y, 3, max_iter=30)
+        np.testing.assert_allclose(st.coef, fit.coef, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(st.r2y, fit.r2y, rtol=1e-8)
+
+
+def test_copy_x_false_leaves_nothing_for_get_q2y():
+    from cmtf_pls_amd import tPLS
+    from cmtf_pls_amd.validate import get_q2y
+    x, y, _ = O.import_synthetic((40, 5, 4), 2, 2, error=0.1, seed=4)
+    m = tPLS(2, copy_X=False)
+    m.fit(torch.from_numpy(x).cuda(), y)
+    assert m.original_X is None and m.X_miss is None
+    with pytest.raises(AssertionError):
+        get_q2y(m)

@@ -1,0 +1,116 @@
+// Experiments (not part of libcmtfpls): access-pattern variants of a row-resident sweep, to find what bounds
+// the read-modify-write kernels.  One workgroup owns one row (row_vec 16-byte vectors) at a time:
+// every lane loads NV vectors (all in flight), optional barrier, then stores them back negated.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int THREADS, int NV, bool BARRIER, bool WRITE>
+__global__ __launch_bounds__(THREADS) void row_kernel(f4* __restrict__ p, int64_t nrows, int64_t rowvec, float* __restrict__ sink) {
+  extern __shared__ float pad[];
+  float acc = 0.f;
+  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    f4* __restrict__ row = p + r * rowvec;
+    f4 v[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) v[n] = __builtin_nontemporal_load(row + threadIdx.x + n * THREADS);
+    if (BARRIER) __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      if (WRITE) __builtin_nontemporal_store(-v[n], row + threadIdx.x + n * THREADS);
+      else acc += (v[n].x + v[n].y) + (v[n].z + v[n].w);
+    }
+  }
+  if (!WRITE && acc == 123.456f) sink[blockIdx.x] = acc;
+}
+
+// software-pipelined: the loads of row r+1 are issued before the stores of row r
+template <int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void row_pipe_kernel(f4* __restrict__ p, int64_t nrows, int64_t rowvec) {
+  int64_t r = blockIdx.x;
+  if (r >= nrows) return;
+  f4 cur[NV], nxt[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) cur[n] = __builtin_nontemporal_load(p + r * rowvec + threadIdx.x + n * THREADS);
+  for (; r < nrows; r += gridDim.x) {
+    const int64_t rn = r + gridDim.x;
+    if (rn < nrows) {
+#pragma unroll
+      for (int n = 0; n < NV; ++n) nxt[n] = __builtin_nontemporal_load(p + rn * rowvec + threadIdx.x + n * THREADS);
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) __builtin_nontemporal_store(-cur[n], p + r * rowvec + threadIdx.x + n * THREADS);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) cur[n] = nxt[n];
+  }
+}
+
+// column-owner layout (the contraction's): a workgroup owns THREADS*NG vectors of columns and a block of rows;
+// RU rows in flight; WRITE: stores back negated
+template <int THREADS, int NG, int RU, bool WRITE>
+__global__ __launch_bounds__(THREADS) void col_kernel(f4* __restrict__ p, int64_t nrows, int64_t rowvec, int rows_per_block, float* __restrict__ sink) {
+  const int64_t c = (int64_t)blockIdx.x * THREADS * NG + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < nrows ? r0 + rows_per_block : nrows;
+  float acc = 0.f;
+  for (int64_t r = r0; r + RU <= r1; r += RU) {
+    f4 v[RU][NG];
+#pragma unroll
+    for (int s = 0; s < RU; ++s)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) v[s][g] = __builtin_nontemporal_load(p + (r + s) * rowvec + c + g * THREADS);
+#pragma unroll
+    for (int s = 0; s < RU; ++s)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (WRITE) __builtin_nontemporal_store(-v[s][g], p + (r + s) * rowvec + c + g * THREADS);
+        else acc += (v[s][g].x + v[s][g].y) + (v[s][g].z + v[s][g].w);
+      }
+  }
+  if (!WRITE && acc == 123.456f) sink[blockIdx.x] = acc;
+}
+
+extern "C" int exp_launch(int kind, void* buf, int64_t nrows, int64_t rowvec, int grid, int lds_pad, float* sink, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  f4* p = (f4*)buf;
+#define ROW(ID, T, NV, B, W) case ID: hipLaunchKernelGGL((row_kernel<T, NV, B, W>), dim3(grid), dim3(T), lds_pad, st, p, nrows, rowvec, sink); break;
+  switch (kind) {
+    ROW(0, 1024, 4, true, true)
+    ROW(1, 1024, 4, false, true)
+    ROW(2, 512, 8, true, true)
+    ROW(3, 512, 8, false, true)
+    ROW(4, 256, 16, true, true)
+    ROW(5, 256, 16, false, true)
+    ROW(6, 1024, 4, false, false)
+    ROW(7, 512, 8, false, false)
+    ROW(8, 256, 16, false, false)
+    ROW(9, 1024, 2, true, true)     // half rows (rowvec = 2048)
+    ROW(10, 1024, 2, false, true)
+    ROW(11, 1024, 1, true, true)    // quarter rows
+    ROW(12, 1024, 8, true, true)    // double rows (rowvec = 8192)
+    ROW(13, 1024, 2, false, false)
+    ROW(14, 1024, 8, false, false)
+    case 20: hipLaunchKernelGGL((row_pipe_kernel<1024, 4>), dim3(grid), dim3(1024), lds_pad, st, p, nrows, rowvec); break;
+    case 21: hipLaunchKernelGGL((row_pipe_kernel<512, 8>), dim3(grid), dim3(512), lds_pad, st, p, nrows, rowvec); break;
+    case 22: hipLaunchKernelGGL((row_pipe_kernel<256, 16>), dim3(grid), dim3(256), lds_pad, st, p, nrows, rowvec); break;
+    // column-owner: grid = total workgroups; col tiles = rowvec / (256 * NG)
+    case 30: { int ct = (int)(rowvec / (256 * 2)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<256, 2, 4, true>), dim3(ct, rb), dim3(256), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 31: { int ct = (int)(rowvec / (256 * 2)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<256, 2, 4, false>), dim3(ct, rb), dim3(256), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 32: { int ct = (int)(rowvec / (256 * 4)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<256, 4, 4, true>), dim3(ct, rb), dim3(256), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 33: { int ct = (int)(rowvec / (256 * 4)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<256, 4, 4, false>), dim3(ct, rb), dim3(256), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 34: { int ct = (int)(rowvec / (256 * 4)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<256, 4, 8, true>), dim3(ct, rb), dim3(256), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 35: { int ct = (int)(rowvec / (1024 * 4)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<1024, 4, 2, true>), dim3(ct, rb), dim3(1024), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 36: { int ct = (int)(rowvec / (1024 * 4)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<1024, 4, 2, false>), dim3(ct, rb), dim3(1024), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 37: { int ct = (int)(rowvec / (1024 * 4)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
+               hipLaunchKernelGGL((col_kernel<1024, 4, 4, false>), dim3(ct, rb), dim3(1024), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    default: return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
