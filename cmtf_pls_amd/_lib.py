@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CMTFPLS_LIB overrides the path (used only by tools/tune_sweeps.sh to A/B kernel variants)
@@ -70,6 +70,8 @@ SIGNATURES = {
     "cmtfpls_khatri_rao_f64": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "cmtfpls_recon_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
     "cmtfpls_recon_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
+    "cmtfpls_add_noise_f32": (c_int, [_P, c_int64, c_double, c_uint64, c_uint64, c_double, _P]),
+    "cmtfpls_add_noise_f64": (c_int, [_P, c_int64, c_double, c_uint64, c_uint64, c_double, _P]),
     "cmtfpls_ceiling_max_blocks": (c_int, []),
     "cmtfpls_ceiling_read": (c_int, [_P, c_size_t, c_int64, _P, c_int, _P]),
     "cmtfpls_ceiling_rmw": (c_int, [_P, c_size_t, c_int64, c_int, _P]),

@@ -314,6 +314,14 @@ class HipBackend:
         _lib.check(rc, "recon")
         return out
 
+    def add_noise(self, X: torch.Tensor, sigma: float, seed: int, offset: int = 0, nan_fraction: float = 0.0) -> torch.Tensor:
+        """X += sigma * N(0,1) in place from the counter-based generator (element e of X is global element offset + e
+        of the stream keyed by seed), then an i.i.d. NaN mask of density nan_fraction (synthetic.py:71,74)."""
+        assert X.is_contiguous() and X.device == self.device
+        _lib.check(self._fn("add_noise", X)(_ptr(X), X.numel(), float(sigma), int(seed) & (2 ** 64 - 1), int(offset), float(nan_fraction),
+                                            self._stream()), "add_noise")
+        return X
+
     def scores_mean(self, Ts: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         nb, I = Ts.shape
         _lib.check(self.lib.cmtfpls_scores_mean_f64(_ptr(Ts), nb, I, _ptr(out), self._stream()), "scores_mean")

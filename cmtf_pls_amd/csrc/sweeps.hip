@@ -275,7 +275,10 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_contract_kernel(
 // 256-thread column-tile form above stops at 5.0 TB/s under the register pressure of its 4 x 2 rows in flight).
 // u = Y q is formed up front by the rowdot kernel (one small launch instead of a per-workgroup prologue).
 // One partial row of Z per workgroup (gridDim / nseg partial rows), summed by reduce_rows_kernel in index order.
-template <typename T, int MODE, bool KC>
+// FULL: every lane's 4 vectors exist (segment = 1024 * V * 4 elements exactly): no guards, straight-line code.
+// MODE 0 (unmasked: the block has no missing value, Z propagates NaN like np.einsum) also drops the NaN test of
+// the norm -- 3 of the 9 vector ALU operations per element.
+template <typename T, int MODE, bool KC, bool FULL>
 __global__ __launch_bounds__(1024) void deflate_contract_rows_kernel(
     T* __restrict__ X, int64_t I, unsigned P, int B, int nseg, const double* __restrict__ t,
     const double* __restrict__ wA, const double* __restrict__ wB, const double* __restrict__ u,
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(1024) void deflate_contract_rows_kernel(
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
     const unsigned c = c0 + n * stride;
-    ok[n] = c < Pseg;
+    ok[n] = FULL || c < Pseg;
     const unsigned cg = seg * Pseg + (ok[n] ? c : 0);
     wa[n] = wA[cg / (unsigned)B];                          // B % V == 0: one j for the whole vector
 #pragma unroll
@@ -315,19 +318,19 @@ __global__ __launch_bounds__(1024) void deflate_contract_rows_kernel(
       tt[q] = t[r + q * step];
 #pragma unroll
       for (int n = 0; n < NV; ++n)
-        if (ok[n]) x[q][n] = ld_stream(reinterpret_cast<const VT*>(xs + (r + q * step) * (int64_t)P + n * stride));
+        if (FULL || ok[n]) x[q][n] = ld_stream(reinterpret_cast<const VT*>(xs + (r + q * step) * (int64_t)P + n * stride));
     }
 #pragma unroll
     for (int q = 0; q < RU; ++q)
 #pragma unroll
       for (int n = 0; n < NV; ++n)
-        if (ok[n]) {
+        if (FULL || ok[n]) {
           const double tw = tt[q] * wa[n];
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             const T nv = (T)fma(-tw, wb[KC ? 0 : n][e], (double)x[q][n].e[e]);
             x[q][n].e[e] = nv;
-            const double d = (nv == nv) ? (double)nv : 0.0;          // NaN (missing) stays NaN, skipped in the norm
+            const double d = (MODE == 0 || nv == nv) ? (double)nv : 0.0;   // NaN (missing) stays NaN, skipped in the norm
             ssq = fma(d, d, ssq);
             acc[n][e] = fma((MODE == 0) ? (double)nv : d, uu[q], acc[n][e]);
           }
@@ -338,14 +341,14 @@ __global__ __launch_bounds__(1024) void deflate_contract_rows_kernel(
     const double ur = u[r], tr = t[r];
 #pragma unroll
     for (int n = 0; n < NV; ++n)
-      if (ok[n]) {
+      if (FULL || ok[n]) {
         VT x = ld_stream(reinterpret_cast<const VT*>(xs + r * (int64_t)P + n * stride));
         const double tw = tr * wa[n];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const T nv = (T)fma(-tw, wb[KC ? 0 : n][e], (double)x.e[e]);
           x.e[e] = nv;
-          const double d = (nv == nv) ? (double)nv : 0.0;
+          const double d = (MODE == 0 || nv == nv) ? (double)nv : 0.0;
           ssq = fma(d, d, ssq);
           acc[n][e] = fma((MODE == 0) ? (double)nv : d, ur, acc[n][e]);
         }
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(1024) void deflate_contract_rows_kernel(
   double* __restrict__ prow = part + (int64_t)(blockIdx.x / nseg) * P + seg * Pseg + c0;
 #pragma unroll
   for (int n = 0; n < NV; ++n)
-    if (ok[n]) {
+    if (FULL || ok[n]) {
 #pragma unroll
       for (int e = 0; e < V; ++e) prow[n * stride + e] = acc[n][e];
     }
@@ -616,9 +619,10 @@ static int run_deflate_contract(T* X, int64_t I, int A, int B, const double* t, 
     if (rc != CMTFPLS_OK) return rc;
     const bool kc = ((1024 * Vt) % B) == 0 && ((P / nseg) % B) == 0;
     const dim3 g(kDcRowsGrid), b(1024);
-#define DCR(MD, K) hipLaunchKernelGGL((deflate_contract_rows_kernel<T, MD, K>), g, b, 0, st, X, I, (unsigned)P, B, nseg, t, wA, wB, u_ws, part, sspart)
-    if (masked) { if (kc) DCR(1, true); else DCR(1, false); }
-    else        { if (kc) DCR(0, true); else DCR(0, false); }
+    const bool full = kc && (P / nseg) == (int64_t)1024 * Vt * 4;
+#define DCR(MD, K, F) hipLaunchKernelGGL((deflate_contract_rows_kernel<T, MD, K, F>), g, b, 0, st, X, I, (unsigned)P, B, nseg, t, wA, wB, u_ws, part, sspart)
+    if (masked) { if (full) DCR(1, true, true); else if (kc) DCR(1, true, false); else DCR(1, false, false); }
+    else        { if (full) DCR(0, true, true); else if (kc) DCR(0, true, false); else DCR(0, false, false); }
 #undef DCR
     launch_reduce_rows(part, (int)nrows_part, P, Z, st);
     launch_reduce_rows(sspart, kDcRowsGrid, 1, ssq, st);

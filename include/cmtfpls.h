@@ -250,6 +250,17 @@ int cmtfpls_recon_f32(const double* T, int64_t I, int ldt, int R, const double* 
 int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
                       const double* mean, double* out, void* stream);
 
+/* ---- synthetic inputs on the device: cmtf_pls/synthetic.py:59-74 (import_synthetic), :5-34 (make_synthetic_test)
+ * The dense CP tensor of the drawn factors is cmtfpls_recon_* with T = the sample factor; add_noise then adds
+ * sigma * N(0,1) in place (synthetic.py:71,74) and, if nan_fraction > 0, plants an i.i.d. NaN mask (BASELINE
+ * configs[3]).  The generator is counter based (Philox4x32-10, key = seed, counter = (offset + e) / 4 for
+ * element e of this buffer; offset = the buffer's first GLOBAL element index): a row shard of a
+ * tensor receives exactly the noise those rows have in the whole tensor. */
+int cmtfpls_add_noise_f32(float* X, int64_t n, double sigma, uint64_t seed, uint64_t offset, double nan_fraction,
+                          void* stream);
+int cmtfpls_add_noise_f64(double* X, int64_t n, double sigma, uint64_t seed, uint64_t offset, double nan_fraction,
+                          void* stream);
+
 /* ---- measured HBM ceilings (the roofline denominator "re-measured with a device copy
  * kernel"; not a reference call site) ---------------------------------------------------------------
  * Plain 16-byte-per-lane non-temporal streaming kernels over `bytes` of a 16-byte-aligned buffer:

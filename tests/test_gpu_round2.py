@@ -166,19 +166,22 @@ def test_reconstruction_on_device_matches_oracle(shape, R, dtype):
 
 
 def test_more_components_than_latent_factors_noise_free():
-    """R above the effective rank on noise-free data.  The reference's lstsq(T, u, rcond=-1) keeps the
-    coefficients of tiny score columns; the meaningful components must agree with the oracle and nothing may be
-    truncated to an all-zero coefficient column."""
+    """R above the effective rank on noise-free data.  With 2 latent factors every score lies in a
+    2-dimensional sample space: T is exactly rank 2 (singular values 59, 22, 5e-15, 4e-15) and the deflated Y is ~0,
+    so the reference's min-norm lstsq(T, u, rcond=-1) returns ~1e-17 for the extra components.  The device solve
+    (equilibrated Cholesky that drops dependent columns) must agree: same meaningful coefficients, ~0 elsewhere,
+    nothing non-finite."""
     from cmtf_pls_amd import tPLS
     x, y, _ = O.import_synthetic((60, 7, 5), 3, 2, error=0.0, seed=12)
     m = tPLS(4)
     m.fit(x, y, max_iter=50)
     fit = O.fit_tpls(x, y, 4, max_iter=50)
-    np.testing.assert_allclose(m.coef_[:2, :2], fit.coef[:2, :2], rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(m.R2Y[:2], fit.r2y[:2], rtol=1e-8)
+    assert np.all(np.isfinite(m.coef_))
+    np.testing.assert_allclose(m.coef_, fit.coef, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(m.X_factors[0][:, :2], fit.T[:, :2], rtol=1e-6, atol=1e-8 * np.abs(fit.T).max())
-    assert np.all(np.isfinite(m.coef_)) and np.all(np.diag(m.coef_) != 0.0)
     assert m.R2Y[-1] > 1 - 1e-10 and fit.r2y[-1] > 1 - 1e-10
+    np.testing.assert_allclose(m.predict(x), O.predict(fit, x), rtol=1e-7, atol=1e-9)
 
 
 def test_fit_epilogue_has_no_host_round_trip():

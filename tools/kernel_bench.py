@@ -80,6 +80,9 @@ def main():
         rec("score_gram (+ Y^T t partials)", lambda: be.score_gram(X, A, B, wa, wb, None, t, Y, qpart), xbytes)
     rec("score masked", lambda: be.score(X, A, B, wa, wb, rowcnt, t), xbytes)
     rec("deflate (r+w)", lambda: be.deflate(X, A, B, tsmall, wa, wb), 2 * xbytes)
+    if args.M <= 64:
+        rec("deflate_contract_yq (r+w)", lambda: be.deflate_contract_yq(X, A, B, tsmall, wa, wb, Y, q, False, out=Z), 2 * xbytes)
+    rec("center (r+w)", lambda: be.center(X, torch.zeros(P, device='cuda:0', dtype=torch.float64), False), 2 * xbytes)
     rec("score_deflate fused (r+w)", lambda: be.score_deflate(X, A, B, wa, wb, None, t2), 2 * xbytes)
     if args.only == "sweeps":
         return

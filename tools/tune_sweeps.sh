@@ -5,13 +5,13 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "k4:-DCMTFPLS_YQ_ROWS_IN_FLIGHT=4" "k8:-DCMTFPLS_YQ_ROWS_IN_FLIGHT=8" "cb1280:-DCMTFPLS_CONTRACT_BLOCKS=1280" "cb1280k4:-DCMTFPLS_CONTRACT_BLOCKS=1280 -DCMTFPLS_YQ_ROWS_IN_FLIGHT=4")
+VARIANTS=("base:" "u4cb1024:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1024" "u4cb1536:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1536" "u4cb2048:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=2048" "u4cb1024r2:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1024 -DCMTFPLS_UNROLL=2" "u4cb1024b:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1024" "base2:" "dcold:-DCMTFPLS_DC_ROWS=0")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
     name="${v%%:*}"; flags="${v#*:}"
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags \
-        "$SRC/runtime.hip" "$SRC/sweeps.hip" "$SRC/small.hip" "$SRC/rank1.hip" "$SRC/rank1_tensor.hip" "$SRC/xcov.hip" "$SRC/mttkrp.hip" "$SRC/mixed.hip" -o "$OUT/libcmtfpls_$name.so" ) &
+        "$SRC"/*.hip -o "$OUT/libcmtfpls_$name.so" ) &
   done
   wait
   ls -la "$OUT"
