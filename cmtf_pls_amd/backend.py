@@ -314,6 +314,29 @@ class HipBackend:
         _lib.check(rc, "recon")
         return out
 
+    def loo_tpls(self, X2: torch.Tensor, Y: torch.Tensor, A: int, B: int, R: int, tol: float, max_iter: int,
+                 max_ws_bytes: int = 4 << 30) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+        """Leave-one-out predictions of a tPLS model (validate.py:24-33), every fold a workgroup: returns
+        (Ypred (I, M), n_iter (I, R)) or None when the shape is outside the one-workgroup-per-fold form."""
+        I, P = X2.shape
+        M = Y.shape[1]
+        assert X2.dtype == torch.float64 and Y.dtype == torch.float64 and X2.is_contiguous() and Y.is_contiguous() and P == A * B
+        per = self.lib.cmtfpls_loo_fold_workspace_bytes(I, A, B, M, R)
+        chunk = max(1, min(I, int(max_ws_bytes // max(per, 1))))
+        ws = self._workspace("loo", per * chunk)
+        colsum_x, _ = self.colstats(X2)
+        colsum_y, _ = self.colstats(Y)
+        Ypred = self.empty(I, M)
+        n_iter = torch.zeros(I, R, dtype=torch.int32, device=self.device)
+        for f0 in range(0, I, chunk):
+            nf = min(chunk, I - f0)
+            rc = self.lib.cmtfpls_loo_tpls_f64(_ptr(X2), _ptr(Y), _ptr(colsum_x), _ptr(colsum_y), I, A, B, M, R, float(tol), int(max_iter),
+                                               f0, nf, _ptr(Ypred), _ptr(n_iter), _ptr(ws), ws.numel(), self._stream())
+            if rc == 4:
+                return None
+            _lib.check(rc, "loo_tpls")
+        return Ypred, n_iter
+
     def add_noise(self, X: torch.Tensor, sigma: float, seed: int, offset: int = 0, nan_fraction: float = 0.0) -> torch.Tensor:
         """X += sigma * N(0,1) in place from the counter-based generator (element e of X is global element offset + e
         of the stream keyed by seed), then an i.i.d. NaN mask of density nan_fraction (synthetic.py:71,74)."""

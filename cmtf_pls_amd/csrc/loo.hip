@@ -1,0 +1,381 @@
+// Leave-one-out refits of a small tPLS model, ALL FOLDS IN ONE LAUNCH: validate.get_q2y (cmtf_pls/validate.py:7-37)
+// refits the model once per held-out sample (validate.py:27-33); each refit is a complete tPLS.fit
+// (tpls.py:73-113) on I - 1 samples followed by predict (tpls.py:122-143) on the one left out.  For the sizes this
+// helper is used at (hundreds of samples, a few thousand columns) one refit is a few hundred tiny launches, i.e. pure
+// launch latency, and the I refits are independent -- so here ONE WORKGROUP owns one fold and runs the whole fit for
+// it (centring, the NIPALS loop with its convergence test, rank-1 extraction, deflation, inner regression, Y
+// deflation, projection of the held-out row) without leaving the kernel; the folds run side by side on the CUs.
+//
+// What is shared between folds instead of recomputed (SURVEY 8(f2) "down-date instead of refitting"): the column
+// sums of X and Y are formed once; fold i's mean is (colsum - row_i) / (I - 1).  The held-out row is zeroed in the
+// fold's centred working copy, which removes it from every sum of the fit without a row gather.
+//
+// Arithmetic: float64 throughout, the operation order of the reference loop; the rank-1 extraction is the product's
+// (Gram matrix of the smaller side squared repeatedly with power-of-two rescaling until numerically rank one, one
+// exact pass with Z, sign rule on the last mode), run inside the workgroup with G in LDS.
+// Limits (the caller falls back to one refit per fold on the regular engine otherwise): X of order 2 or 3 without
+// missing values, min(A, B) <= 64, M <= 64, R <= 16, and the per-workgroup vectors must fit 150 KB of LDS.
+#include "common.hpp"
+
+namespace cmtfpls {
+
+constexpr int kLooThreads = 256;
+constexpr int kLooMaxN = 64, kLooMaxR = 16, kLooMaxM = 64;
+
+struct LooArgs {
+  const double* X;        // (I, P) original, uncentred
+  const double* Y;        // (I, M)
+  const double* colsum_x; // (P)
+  const double* colsum_y; // (M)
+  double* ws;             // per resident fold: Xf (I*P) | Yf (I*M) | T (I*R)
+  double* Ypred;          // (I, M): row i = prediction of the model fitted without sample i
+  int* n_iter;            // (I, R) inner iterations executed (nullable)
+  int64_t ws_per_fold;    // doubles
+  int I, A, B, M, R, max_iter, fold0, nfolds;
+  double tol;
+};
+
+// sum over the workgroup; every thread gets the same value; two barriers, so back-to-back calls may share `red`
+__device__ __forceinline__ double loo_sum(double v, double* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < kLooThreads / 64; ++w) s += red[w];
+  __syncthreads();
+  return s;
+}
+
+// Leading singular pair of Z (A x B row-major in LDS): wA (A), wB (B) unit norm, largest-|.| entry of wB positive.
+// G0/G1: n*n doubles each; xs: n; ys: k (n = min(A,B), k = max(A,B)).  All threads must call it.
+__device__ void loo_rank1(const double* Z, int A, int B, double* wA, double* wB, double* G0, double* G1, double* xs, double* ys,
+                          double* red, int* ired) {
+  const int tid = threadIdx.x;
+  const bool rowsA = A <= B;                        // M = Z (n = A) or Z^T (n = B)
+  const int n = rowsA ? A : B, k = rowsA ? B : A;
+#define LOO_M(i, l) (rowsA ? Z[(i) * B + (l)] : Z[(l) * B + (i)])
+  for (int o = tid; o < n * n; o += kLooThreads) {
+    const int i = o / n, j = o % n;
+    double s = 0.0;
+    for (int l = 0; l < k; ++l) s = fma(LOO_M(i, l), LOO_M(j, l), s);
+    G0[o] = s;
+  }
+  __syncthreads();
+  double* G = G0;
+  double* Gn = G1;
+  for (int step = 0; step < 64; ++step) {
+    double trp = 0.0, frp = 0.0;
+    for (int o = tid; o < n * n; o += kLooThreads) {
+      const double g = G[o];
+      frp = fma(g, g, frp);
+      if (o / n == o % n) trp += g;
+    }
+    const double tr = loo_sum(trp, red), fro = loo_sum(frp, red);
+    if (!(tr > 0.0) || !isfinite(tr) || fro / (tr * tr) >= 1.0 - 1e-13) break;      // uniform
+    int e;
+    frexp(tr, &e);
+    const double sc = ldexp(1.0, -e), sc2 = sc * sc;                              // exact power of two
+    for (int o = tid; o < n * n; o += kLooThreads) {
+      const int i = o / n, j = o % n;
+      double s = 0.0;
+      for (int l = 0; l < n; ++l) s = fma(G[i * n + l], G[j * n + l], s);          // G symmetric: row j = column j
+      Gn[o] = s * sc2;
+    }
+    __syncthreads();
+    double* tmp = G; G = Gn; Gn = tmp;
+  }
+  // seed = dominant column of G (first index on ties), normalised
+  if (tid == 0) {
+    double bv = -1.0;
+    int bi = 0;
+    for (int i = 0; i < n; ++i) { const double dd = G[i * n + i]; if (dd > bv) { bv = dd; bi = i; } }
+    ired[0] = bi;
+  }
+  __syncthreads();
+  const int bi = ired[0];
+  double ss = 0.0;
+  for (int i = tid; i < n; i += kLooThreads) { const double g = G[bi * n + i]; ss = fma(g, g, ss); }
+  const double snrm = sqrt(loo_sum(ss, red));
+  for (int i = tid; i < n; i += kLooThreads) xs[i] = G[bi * n + i] / snrm;          // xs = seed for now
+  __syncthreads();
+  for (int l = tid; l < k; l += kLooThreads) {                                       // y = M^T seed
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s = fma(LOO_M(i, l), xs[i], s);
+    ys[l] = s;
+  }
+  __syncthreads();
+  double xv = 0.0;                                                                   // x = M y (n <= 64 <= threads)
+  if (tid < n) { for (int l = 0; l < k; ++l) xv = fma(LOO_M(tid, l), ys[l], xv); }
+  __syncthreads();
+  if (tid < n) xs[tid] = xv;
+  __syncthreads();
+#undef LOO_M
+  double sx = 0.0, sy = 0.0;
+  for (int i = tid; i < n; i += kLooThreads) sx = fma(xs[i], xs[i], sx);
+  for (int l = tid; l < k; l += kLooThreads) sy = fma(ys[l], ys[l], sy);
+  const double nx = sqrt(loo_sum(sx, red)), ny = sqrt(loo_sum(sy, red));
+  // sign rule on the LAST mode's vector wB: its largest-|.| entry is positive (first index on ties)
+  const double* vb = rowsA ? ys : xs;
+  const int nb = rowsA ? k : n;
+  if (tid == 0) {
+    double bv = -1.0;
+    int b2 = 0;
+    for (int i = 0; i < nb; ++i) { const double dd = fabs(vb[i]); if (dd > bv) { bv = dd; b2 = i; } }
+    ired[1] = (vb[b2] < 0.0) ? -1 : 1;
+  }
+  __syncthreads();
+  const double sgn = (double)ired[1];
+  double* ox = rowsA ? wA : wB;
+  double* oy = rowsA ? wB : wA;
+  for (int i = tid; i < n; i += kLooThreads) ox[i] = sgn * (xs[i] / nx);
+  for (int l = tid; l < k; l += kLooThreads) oy[l] = sgn * (ys[l] / ny);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
+  extern __shared__ double sm[];
+  __shared__ double red[8];
+  __shared__ int ired[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int I = a.I, A = a.A, B = a.B, M = a.M, R = a.R, P = A * B;
+  const int n = A < B ? A : B, k = A < B ? B : A;
+  const int fold = a.fold0 + blockIdx.x;
+  if (blockIdx.x >= a.nfolds || fold >= I) return;
+  double* Xf = a.ws + (int64_t)blockIdx.x * a.ws_per_fold;
+  double* Yf = Xf + (int64_t)I * P;
+  double* T = Yf + (int64_t)I * M;
+  // LDS carve-up
+  double* u = sm;
+  double* t = u + I;
+  double* Z = t + I;
+  double* wA = Z + P;
+  double* wB = wA + A;
+  double* q = wB + B;
+  double* qn = q + M;
+  double* G0 = qn + M;
+  double* G1 = G0 + n * n;
+  double* xs = G1 + n * n;
+  double* ys = xs + n;
+  double* my = ys + k;            // mean of Y over the training rows
+  double* coef = my + M;          // R x R
+  double* Wa = coef + R * R;      // R x A
+  double* Wb = Wa + R * A;        // R x B
+  double* Qs = Wb + R * B;        // R x M
+  double* Gn = Qs + R * M;        // (a+1) x (a+1) normal equations
+  double* gn = Gn + R * R;
+  double* bb = gn + R;
+  double* dd = bb + R;
+  const double inv = 1.0 / (double)(I - 1);
+
+  // ---- preprocess (tpls.py:61-71): means over the I - 1 training rows by down-dating the column sums; the
+  // held-out row is zero in the working copies, i.e. absent from every sum below
+  for (int m = tid; m < M; m += kLooThreads) my[m] = (a.colsum_y[m] - a.Y[(int64_t)fold * M + m]) * inv;
+  for (int o = tid; o < R * R; o += kLooThreads) coef[o] = 0.0;
+  __syncthreads();
+  for (int c = tid; c < P; c += kLooThreads) {
+    const double mu = (a.colsum_x[c] - a.X[(int64_t)fold * P + c]) * inv;
+    Z[c] = mu;                                            // kept in Z until the first iteration overwrites it
+  }
+  __syncthreads();
+  for (int64_t idx = tid; idx < (int64_t)I * P; idx += kLooThreads) {
+    const int r = (int)(idx / P), c = (int)(idx % P);
+    Xf[idx] = (r == fold) ? 0.0 : a.X[idx] - Z[c];
+  }
+  for (int64_t idx = tid; idx < (int64_t)I * M; idx += kLooThreads) {
+    const int r = (int)(idx / M), m = (int)(idx % M);
+    Yf[idx] = (r == fold) ? 0.0 : a.Y[idx] - my[m];
+  }
+  __syncthreads();
+
+  for (int comp = 0; comp < R; ++comp) {
+    for (int r = tid; r < I; r += kLooThreads) u[r] = Yf[(int64_t)r * M];             // tpls.py:78
+    __syncthreads();
+    int it = 0;
+    for (; it < a.max_iter; ++it) {                                                    // tpls.py:79
+      // Z = X x_0 u (tpls.py:83): a thread owns columns, rows stream past (coalesced across the workgroup)
+      for (int c = tid; c < P; c += kLooThreads) {
+        double s = 0.0;
+        for (int r = 0; r < I; ++r) s = fma(Xf[(int64_t)r * P + c], u[r], s);
+        Z[c] = s;
+      }
+      __syncthreads();
+      if (A == 1) {                                                                    // tpls.py:84: Z / norm(Z)
+        double s = 0.0;
+        for (int c = tid; c < P; c += kLooThreads) s = fma(Z[c], Z[c], s);
+        const double nz = sqrt(loo_sum(s, red));
+        for (int c = tid; c < P; c += kLooThreads) wB[c] = Z[c] / nz;
+        if (tid == 0) wA[0] = 1.0;
+        __syncthreads();
+      } else {
+        loo_rank1(Z, A, B, wA, wB, G0, G1, xs, ys, red, ired);                         // tpls.py:86-88
+      }
+      // t = X x_1 wA x_2 wB (tpls.py:97-99): one wavefront per row
+      for (int r = wv; r < I; r += kLooThreads / 64) {
+        double s = 0.0;
+        for (int c = lane; c < P; c += 64) s = fma(Xf[(int64_t)r * P + c], wA[c / B] * wB[c % B], s);
+        s = wave_sum(s);
+        if (lane == 0) t[r] = s;
+      }
+      __syncthreads();
+      // q = Y^T t / |.| (tpls.py:100-101)
+      if (tid < M) {
+        double s = 0.0;
+        for (int r = 0; r < I; ++r) s = fma(Yf[(int64_t)r * M + tid], t[r], s);
+        q[tid] = s;
+      }
+      __syncthreads();
+      double qs = (tid < M) ? q[tid] * q[tid] : 0.0;
+      const double qnrm = sqrt(loo_sum(qs, red));
+      if (tid < M) qn[tid] = q[tid] / qnrm;
+      __syncthreads();
+      // u = Y q and |u_old - u| (tpls.py:102-103)
+      double du2 = 0.0;
+      for (int r = tid; r < I; r += kLooThreads) {
+        double s = 0.0;
+        for (int m = 0; m < M; ++m) s = fma(Yf[(int64_t)r * M + m], qn[m], s);
+        const double d0 = u[r] - s;
+        du2 = fma(d0, d0, du2);
+        u[r] = s;
+      }
+      const double du = sqrt(loo_sum(du2, red));
+      if (it > 0 && du < a.tol) { ++it; break; }                                       // first pass: oldU = inf (tpls.py:77)
+    }
+    if (a.n_iter && tid == 0) a.n_iter[(int64_t)fold * R + comp] = it;
+    // store the component; deflate X (tpls.py:109)
+    for (int r = tid; r < I; r += kLooThreads) T[(int64_t)r * R + comp] = t[r];
+    for (int j = tid; j < A; j += kLooThreads) Wa[comp * A + j] = wA[j];
+    for (int j = tid; j < B; j += kLooThreads) Wb[comp * B + j] = wB[j];
+    for (int m = tid; m < M; m += kLooThreads) Qs[comp * M + m] = qn[m];
+    for (int64_t idx = tid; idx < (int64_t)I * P; idx += kLooThreads) {
+      const int r = (int)(idx / P), c = (int)(idx % P);
+      Xf[idx] -= t[r] * (wA[c / B] * wB[c % B]);
+    }
+    __syncthreads();
+    // inner regression b = lstsq(T[:, :k], u) (tpls.py:110-112): normal equations, equilibrated Cholesky
+    const int kk = comp + 1;
+    for (int o = tid; o < kk * kk + kk; o += kLooThreads) {
+      double s = 0.0;
+      if (o < kk * kk) {
+        const int p = o / kk, s2 = o % kk;
+        for (int r = 0; r < I; ++r) s = fma(T[(int64_t)r * R + p], T[(int64_t)r * R + s2], s);
+        Gn[o] = s;
+      } else {
+        const int p = o - kk * kk;
+        for (int r = 0; r < I; ++r) s = fma(T[(int64_t)r * R + p], u[r], s);
+        gn[p] = s;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double tiny = (double)kk * 2.220446049250313e-16;
+      for (int i = 0; i < kk; ++i) { const double g = Gn[i * kk + i]; dd[i] = (g > 0.0 && isfinite(g)) ? 1.0 / sqrt(g) : 0.0; }
+      for (int i = 0; i < kk; ++i) {
+        for (int j = 0; j < kk; ++j) Gn[i * kk + j] *= dd[i] * dd[j];
+        bb[i] = gn[i] * dd[i];
+      }
+      bool dep[kLooMaxR];
+      for (int c = 0; c < kk; ++c) {
+        const double piv = Gn[c * kk + c];
+        dep[c] = !(piv > tiny);
+        if (dep[c]) { Gn[c * kk + c] = 1.0; for (int i = c + 1; i < kk; ++i) Gn[i * kk + c] = 0.0; continue; }
+        const double l = sqrt(piv);
+        Gn[c * kk + c] = l;
+        for (int i = c + 1; i < kk; ++i) Gn[i * kk + c] /= l;
+        for (int i = c + 1; i < kk; ++i)
+          for (int j = c + 1; j <= i; ++j) Gn[i * kk + j] -= Gn[i * kk + c] * Gn[j * kk + c];
+      }
+      for (int r = 0; r < kk; ++r) {
+        double s = bb[r];
+        for (int j = 0; j < r; ++j) s -= Gn[r * kk + j] * bb[j];
+        bb[r] = dep[r] ? 0.0 : s / Gn[r * kk + r];
+      }
+      for (int r = kk - 1; r >= 0; --r) {
+        double s = bb[r];
+        for (int j = r + 1; j < kk; ++j) s -= Gn[j * kk + r] * bb[j];
+        bb[r] = dep[r] ? 0.0 : s / Gn[r * kk + r];
+      }
+      for (int r = 0; r < kk; ++r) { bb[r] *= dd[r]; coef[r * R + comp] = bb[r]; }
+    }
+    __syncthreads();
+    // Y -= T b q^T (tpls.py:113); t is free: reuse it for yhat = T b
+    for (int r = tid; r < I; r += kLooThreads) {
+      double s = 0.0;
+      for (int j = 0; j < kk; ++j) s = fma(T[(int64_t)r * R + j], bb[j], s);
+      t[r] = s;
+    }
+    __syncthreads();
+    for (int64_t idx = tid; idx < (int64_t)I * M; idx += kLooThreads) {
+      const int r = (int)(idx / M), m = (int)(idx % M);
+      Yf[idx] -= t[r] * qn[m];
+    }
+    __syncthreads();
+  }
+
+  // ---- predict the held-out sample (tpls.py:122-143): centre with the fold's means, project and deflate
+  for (int c = tid; c < P; c += kLooThreads) Z[c] = a.X[(int64_t)fold * P + c] - (a.colsum_x[c] - a.X[(int64_t)fold * P + c]) * inv;
+  __syncthreads();
+  double* sc = u;                                                                       // scores of the held-out row (R)
+  for (int comp = 0; comp < R; ++comp) {
+    double s = 0.0;
+    for (int c = tid; c < P; c += kLooThreads) s = fma(Z[c], Wa[comp * A + c / B] * Wb[comp * B + c % B], s);
+    const double sv = loo_sum(s, red);
+    if (tid == 0) sc[comp] = sv;
+    for (int c = tid; c < P; c += kLooThreads) Z[c] -= sv * (Wa[comp * A + c / B] * Wb[comp * B + c % B]);
+    __syncthreads();
+  }
+  for (int m = tid; m < M; m += kLooThreads) {
+    double yv = 0.0;
+    for (int b2 = 0; b2 < R; ++b2) {
+      double sb = 0.0;
+      for (int a2 = 0; a2 < R; ++a2) sb = fma(sc[a2], coef[a2 * R + b2], sb);        // (scores @ coef_)[b]
+      yv = fma(sb, Qs[b2 * M + m], yv);                                             // @ Q^T
+    }
+    a.Ypred[(int64_t)fold * M + m] = yv + my[m];
+  }
+}
+
+static size_t loo_lds_bytes(int I, int A, int B, int M, int R) {
+  const size_t n = (size_t)(A < B ? A : B), k = (size_t)(A < B ? B : A), P = (size_t)A * B;
+  const size_t dbl = 2 * (size_t)I + P + A + B + 2 * (size_t)M + 2 * n * n + n + k + M + (size_t)R * R + (size_t)R * (A + B) +
+                     (size_t)R * M + (size_t)R * R + 3 * (size_t)R;
+  return dbl * sizeof(double);
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+
+size_t cmtfpls_loo_fold_workspace_bytes(int I, int A, int B, int M, int R) {
+  if (I <= 1 || A <= 0 || B <= 0 || M <= 0 || R <= 0) return 0;
+  return ((size_t)I * A * B + (size_t)I * M + (size_t)I * R) * sizeof(double);
+}
+
+int cmtfpls_loo_tpls_f64(const double* X, const double* Y, const double* colsum_x, const double* colsum_y, int I, int A, int B, int M,
+                         int R, double tol, int max_iter, int fold0, int nfolds, double* Ypred, int* n_iter, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!X || !Y || !colsum_x || !colsum_y || !Ypred || I <= 1 || A <= 0 || B <= 0 || M <= 0 || R <= 0 || max_iter <= 0 || fold0 < 0 ||
+      nfolds <= 0 || fold0 + nfolds > I) {
+    set_error("loo_tpls: bad argument");
+    return CMTFPLS_EINVAL;
+  }
+  const int n = A < B ? A : B;
+  const size_t lds = loo_lds_bytes(I, A, B, M, R);
+  if (n > kLooMaxN || M > kLooMaxM || R > kLooMaxR || lds > 150 * 1024) {
+    set_error("loo_tpls: shape outside the one-workgroup-per-fold form; refit per fold on the regular engine");
+    return CMTFPLS_EUNSUPPORTED;
+  }
+  const size_t per = cmtfpls_loo_fold_workspace_bytes(I, A, B, M, R);
+  if (!ws || ws_bytes < per * (size_t)nfolds) { set_error("loo_tpls: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  LooArgs a;
+  a.X = X; a.Y = Y; a.colsum_x = colsum_x; a.colsum_y = colsum_y; a.ws = static_cast<double*>(ws); a.Ypred = Ypred; a.n_iter = n_iter;
+  a.ws_per_fold = (int64_t)(per / sizeof(double));
+  a.I = I; a.A = A; a.B = B; a.M = M; a.R = R; a.max_iter = max_iter; a.fold0 = fold0; a.nfolds = nfolds; a.tol = tol;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(loo_tpls_kernel, dim3(nfolds), dim3(kLooThreads), lds, (hipStream_t)stream, a);
+  return check_launch("loo_tpls");
+}
+
+}  // extern "C"

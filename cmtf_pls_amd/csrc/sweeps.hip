@@ -16,7 +16,7 @@ namespace cmtfpls {
 // mode-0 contraction / column statistics
 // ------------------------------------------------------------------------------------------
 #ifndef CMTFPLS_CONTRACT_U
-#define CMTFPLS_CONTRACT_U 2
+#define CMTFPLS_CONTRACT_U 4   // 4 groups x 1024 workgroups: +2.8 % over 2 x 1024 at 65536 x 128 x 128 (profiles/r02d_tune_sweeps.txt)
 #endif
 constexpr int kContractU = CMTFPLS_CONTRACT_U;  // 16-byte column groups per thread
 constexpr int kYqChunk = 2048;  // rows of u = Y q a workgroup keeps in LDS at a time (YQ variants)
@@ -32,11 +32,13 @@ struct ContractPlan {
   int rows_per_block;
 };
 
-static ContractPlan plan_contract(int64_t I, int64_t P, int elem) {
+constexpr int kDcU = 2;   // column groups per thread of deflate_contract_kernel (it also keeps wB entries and writes back)
+
+static ContractPlan plan_contract(int64_t I, int64_t P, int elem, int U = kContractU) {
   ContractPlan p;
   const int V = 16 / elem;
   p.vec = (P % V == 0) ? 1 : 0;
-  const int64_t tile = p.vec ? (int64_t)kSweepThreads * V * kContractU : kSweepThreads;
+  const int64_t tile = p.vec ? (int64_t)kSweepThreads * V * U : kSweepThreads;
   p.col_tiles = (int)((P + tile - 1) / tile);
   int64_t want = (kContractBlocks + p.col_tiles - 1) / p.col_tiles;   // ~1024 workgroups in all
   if (want < 1) want = 1;
@@ -75,14 +77,13 @@ __device__ __forceinline__ void rows_times_q(const double* __restrict__ Y, int l
 
 // MODE 0: plain (NaN propagates, as np.einsum)  1: NaN -> 0  2: statistics (u == 1, NaN -> 0, count)
 // YQ: u is not read; u[i] = Y[i, :] . q is formed per workgroup in LDS, kYqChunk rows at a time
-template <typename T, int MODE, bool YQ>
+template <typename T, int MODE, bool YQ, int U>
 __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
     double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block,
     const double* __restrict__ Y, int ldy, int M, const double* __restrict__ q) {
   extern __shared__ double us[];
   constexpr int V = VecOf<T>::N;
-  constexpr int U = kContractU;
   using VT = typename VecOf<T>::type;
   const int64_t cbase = (int64_t)blockIdx.x * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kSweepThreads) void deflate_contract_kernel(
   extern __shared__ double us[];
   __shared__ double red[16];
   constexpr int V = VecOf<T>::N;
-  constexpr int U = kContractU;
+  constexpr int U = kDcU;
   using VT = typename VecOf<T>::type;
   const int64_t cbase = (int64_t)blockIdx.x * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
   const int64_t rb0 = (int64_t)blockIdx.y * rows_per_block;
@@ -541,7 +542,8 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
     return CMTFPLS_EINVAL;
   }
   if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) { set_error("X must be 16-byte aligned"); return CMTFPLS_EINVAL; }
-  const ContractPlan p = plan_contract(I, P, (int)sizeof(T));
+  constexpr int U = (MODE == 2) ? 2 : kContractU;      // the statistics pass carries a second set of accumulators
+  const ContractPlan p = plan_contract(I, P, (int)sizeof(T), U);
   // Wide blocks (>= kYqUnfuseTiles column tiles): every column tile of a row block would repeat the same
   // u = Y q prologue, so u is formed once by the rowdot kernel into the tail of the workspace instead
   // (262144 x 256 x 256, M = 32: 2 % of the sweep)
@@ -559,7 +561,7 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
     double* u_ws = part + (size_t)p.row_blocks * P;
     const int rc = cmtfpls_rowdot_f64(Y, ldy, M, I, q, u_ws, nullptr, nullptr, nullptr, 0, st);
     if (rc != CMTFPLS_OK) return rc;
-    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u_ws, part, cntpart,
+    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false, U>), grid, dim3(kSweepThreads), 0, st, X, I, P, u_ws, part, cntpart,
                        p.rows_per_block, nullptr, 0, 0, nullptr);
   } else if (yq) {
     // supported: vector shape, M <= 64 (one Y row per wavefront pass)
@@ -572,13 +574,13 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
       hipLaunchKernelGGL((contract_narrow_kernel<T, MODE, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
                          p.rows_per_block, Y, ldy, M, q, ncv, RS);
     else
-      hipLaunchKernelGGL((contract_vec_kernel<T, MODE, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
+      hipLaunchKernelGGL((contract_vec_kernel<T, MODE, true, U>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
                          p.rows_per_block, Y, ldy, M, q);
   } else if (narrow) {
     hipLaunchKernelGGL((contract_narrow_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
                        p.rows_per_block, nullptr, 0, 0, nullptr, ncv, RS);
   } else if (p.vec) {
-    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
+    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false, U>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
                        p.rows_per_block, nullptr, 0, 0, nullptr);
   } else {
     hipLaunchKernelGGL((contract_scalar_kernel<T, MODE>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart, p.rows_per_block);
@@ -598,7 +600,7 @@ static int run_deflate_contract(T* X, int64_t I, int A, int B, const double* t, 
   }
   const int64_t P = (int64_t)A * B;
   constexpr int Vt = 16 / (int)sizeof(T);
-  const ContractPlan p = plan_contract(I, P, (int)sizeof(T));
+  const ContractPlan p = plan_contract(I, P, (int)sizeof(T), kDcU);
   if (!p.vec || (B % Vt) != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || M > 64) {
     set_error("deflate_contract_yq: shape outside the fused form; use deflate, then mode0_contract");
     return CMTFPLS_EUNSUPPORTED;
@@ -1278,9 +1280,10 @@ int cmtfpls_sweep_partials(void) { return kSweepBlocks; }
 
 size_t cmtfpls_mode0_contract_workspace_bytes(int64_t I, int64_t P) {
   if (I <= 0 || P <= 0) return 0;
-  // the f64 plan never has fewer row blocks than the f32 plan for the same shape: size for both
-  const ContractPlan a = plan_contract(I, P, 4), b = plan_contract(I, P, 8);
-  const int rb = a.row_blocks > b.row_blocks ? a.row_blocks : b.row_blocks;
+  // sized for every plan a call may choose (f32 / f64 vectors, the statistics pass's narrower column tiles)
+  int rb = 1;
+  for (int elem = 4; elem <= 8; elem += 4)
+    for (int U = 2; U <= kContractU; U += 2) { const int r = plan_contract(I, P, elem, U).row_blocks; if (r > rb) rb = r; }
   return (size_t)rb * (size_t)P * sizeof(double) + (size_t)I * sizeof(double);   // + u = Y q of the wide-block form
 }
 size_t cmtfpls_colstats_workspace_bytes(int64_t I, int64_t P) { return 2 * cmtfpls_mode0_contract_workspace_bytes(I, P); }
@@ -1311,7 +1314,7 @@ int cmtfpls_mode0_contract_yq_f64(const double* X, int64_t I, int64_t P, const d
 }
 size_t cmtfpls_deflate_contract_workspace_bytes(int64_t I, int64_t P) {
   if (I <= 0 || P <= 0) return 0;
-  const ContractPlan a = plan_contract(I, P, 4), b = plan_contract(I, P, 8);
+  const ContractPlan a = plan_contract(I, P, 4, kDcU), b = plan_contract(I, P, 8, kDcU);
   const size_t na = (size_t)a.row_blocks * ((size_t)P + a.col_tiles), nb = (size_t)b.row_blocks * ((size_t)P + b.col_tiles);
   const size_t colform = ((na > nb ? na : nb) + (size_t)I) * sizeof(double);   // + u = Y q of the wide-block form
   // workgroup-per-row-segment form: at most kDcRowsGrid partial rows of P doubles, the ssq partials, u = Y q

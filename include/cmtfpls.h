@@ -250,6 +250,19 @@ int cmtfpls_recon_f32(const double* T, int64_t I, int ldt, int R, const double* 
 int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
                       const double* mean, double* out, void* stream);
 
+/* ---- leave-one-out refits, all folds in one launch: validate.get_q2y  (cmtf_pls/validate.py:7-37) ------------
+ * For every fold i in [fold0, fold0 + nfolds): a complete tPLS fit (tpls.py:73-113; R components, tol, max_iter, the
+ * reference's loop and convergence test) on the I - 1 samples other than i, then predict (tpls.py:122-143) of sample
+ * i into Ypred[i, :].  One workgroup per fold; X (I x A*B) and Y (I x M) are the ORIGINAL float64 data; colsum_x /
+ * colsum_y are their column sums (fold means are down-dated from them).  n_iter (nullable, I x R ints): inner
+ * iterations executed.  ws >= nfolds * cmtfpls_loo_fold_workspace_bytes(...).  X of order 2 (A = 1) or 3 without
+ * missing values; CMTFPLS_EUNSUPPORTED when min(A, B) > 64, M > 64, R > 16 or the per-fold vectors exceed the LDS
+ * (the caller then refits per fold with the regular entry points). */
+size_t cmtfpls_loo_fold_workspace_bytes(int I, int A, int B, int M, int R);
+int cmtfpls_loo_tpls_f64(const double* X, const double* Y, const double* colsum_x, const double* colsum_y, int I, int A,
+                         int B, int M, int R, double tol, int max_iter, int fold0, int nfolds, double* Ypred,
+                         int* n_iter, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- synthetic inputs on the device: cmtf_pls/synthetic.py:59-74 (import_synthetic), :5-34 (make_synthetic_test)
  * The dense CP tensor of the drawn factors is cmtfpls_recon_* with T = the sample factor; add_noise then adds
  * sigma * N(0,1) in place (synthetic.py:71,74) and, if nan_fraction > 0, plants an i.i.d. NaN mask (BASELINE

@@ -231,3 +231,41 @@ def test_copy_x_false_leaves_nothing_for_get_q2y():
     assert m.original_X is None and m.X_miss is None
     with pytest.raises(AssertionError):
         get_q2y(m)
+
+
+# ---- leave-one-out on the device: all folds in one launch (validate.py:24-33) ---------------
+@pytest.mark.parametrize("shape,M,R", [((60, 10, 8), 4, 3), ((40, 8, 10), 1, 2), ((50, 30), 3, 3), ((45, 12, 5), 2, 4)])
+def test_loo_all_folds_in_one_launch_matches_literal_refits(shape, M, R):
+    """get_q2y through cmtfpls_loo_tpls_f64 == the literal leave-one-out over the oracle (fit on I - 1 samples, predict
+    the held-out one), to 1e-8 in Q2Y and 1e-7 per prediction; also == the per-fold refits on the regular engine."""
+    from cmtf_pls_amd import tPLS
+    from cmtf_pls_amd.validate import get_q2y, loo_predictions
+    x, y, _ = O.import_synthetic(shape, M, R, error=0.3, seed=21)
+    m = tPLS(R)
+    m.fit(x, y)
+    pred = loo_predictions(m)
+    assert pred is not None and pred.shape == y.shape
+    I = shape[0]
+    want = np.zeros_like(y)
+    for i in range(I):
+        keep = np.arange(I) != i
+        want[i] = O.predict(O.fit_tpls(x[keep], y[keep], R), x[i:i + 1]).reshape(want[i].shape)
+    np.testing.assert_allclose(pred, want, rtol=1e-7, atol=1e-7 * np.abs(y).max())
+    q_want = 1 - ((want - y) ** 2).sum() / (y ** 2).sum()
+    assert abs(get_q2y(m) - q_want) < 1e-8
+    assert abs(get_q2y(m, device_folds=False) - q_want) < 1e-8
+
+
+def test_loo_declines_shapes_outside_its_form():
+    from cmtf_pls_amd import tPLS
+    from cmtf_pls_amd.validate import get_q2y, loo_predictions
+    x, y, _ = O.import_synthetic((12, 4, 3, 2), 2, 2, error=0.3, seed=22)      # order 4: per-fold refits
+    m = tPLS(2)
+    m.fit(x, y)
+    assert loo_predictions(m) is None
+    assert np.isfinite(get_q2y(m))
+    x3, y3, _ = O.import_synthetic((14, 5, 4), 2, 2, error=0.3, seed=6)
+    x3[2, 1, 1] = np.nan                                                          # missing values: per-fold refits
+    m3 = tPLS(2)
+    m3.fit(x3, y3)
+    assert loo_predictions(m3) is None and np.isfinite(get_q2y(m3))

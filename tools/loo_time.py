@@ -11,7 +11,10 @@ for shape, M, R in (((200, 10, 8), 4, 3), ((100, 38, 65), 3, 4)):
     for algo in ("direct", "xcov"):
         m = tPLS(R, algorithm=algo)
         m.fit(x, y)
-        t0 = time.perf_counter()
-        q = get_q2y(m)
-        dt = time.perf_counter() - t0
-        print(shape, algo, "q2y", round(q, 6), "LOO seconds", round(dt, 3), "per fold ms", round(dt / shape[0] * 1e3, 2), flush=True)
+        for dev_folds in (False, True):
+            get_q2y(m, device_folds=dev_folds) if dev_folds else None      # warm (module load, workspaces)
+            t0 = time.perf_counter()
+            q = get_q2y(m, device_folds=dev_folds)
+            dt = time.perf_counter() - t0
+            print(shape, algo, "all folds in one launch" if dev_folds else "one refit per fold", "q2y", round(q, 8), "LOO seconds", round(dt, 4),
+                  "per fold ms", round(dt / shape[0] * 1e3, 4), flush=True)
