@@ -40,24 +40,26 @@ __device__ __forceinline__ void normals4(uint64_t counter, uint64_t key, double 
 
 // X[e] += sigma * N(0,1)[offset + e];  then X[e] = NaN where U(0,1)[offset + e] < nan_fraction
 template <typename T>
-__global__ __launch_bounds__(256) void add_noise_kernel(T* __restrict__ X, int64_t n, double sigma, uint64_t seed, uint64_t offset,
-                                                       double nan_fraction) {
-  // thread = one GLOBAL quad of the stream (4 consecutive global elements share one Philox block); a buffer that
-  // starts or ends inside a quad uses only its own elements of it
-  const uint64_t gq = (offset >> 2) + (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t e0 = (int64_t)(gq * 4 - offset);                // local index of the quad's first element (may be < 0)
-  if (e0 >= n) return;
-  double z[4] = {0.0, 0.0, 0.0, 0.0};
-  if (sigma != 0.0) normals4(gq, seed, z);
-  Philox4 m{{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}};
-  if (nan_fraction > 0.0) m = philox4x32_10(gq, 1u, seed);
+__global__ __launch_bounds__(256) void add_noise_kernel(T* __restrict__ X, int64_t n, int64_t nquads, double sigma, uint64_t seed,
+                                                       uint64_t offset, double nan_fraction) {
+  // thread = one GLOBAL quad of the stream at a time (4 consecutive global elements share one Philox block), grid
+  // stride over the quads; a buffer that starts or ends inside a quad uses only its own elements of it
+  const uint64_t q0 = offset >> 2;
+  for (int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x; qi < nquads; qi += (int64_t)gridDim.x * 256) {
+    const uint64_t gq = q0 + (uint64_t)qi;
+    const int64_t e0 = (int64_t)(gq * 4 - offset);              // local index of the quad's first element (may be < 0)
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+    if (sigma != 0.0) normals4(gq, seed, z);
+    Philox4 m{{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}};
+    if (nan_fraction > 0.0) m = philox4x32_10(gq, 1u, seed);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int64_t e = e0 + k;
-    if (e >= 0 && e < n) {
-      T v = (T)((double)X[e] + sigma * z[k]);
-      if (nan_fraction > 0.0 && unit_open(m.v[k]) < nan_fraction) v = (T)NAN;
-      X[e] = v;
+    for (int k = 0; k < 4; ++k) {
+      const int64_t e = e0 + k;
+      if (e >= 0 && e < n) {
+        T v = (T)((double)X[e] + sigma * z[k]);
+        if (nan_fraction > 0.0 && unit_open(m.v[k]) < nan_fraction) v = (T)NAN;
+        X[e] = v;
+      }
     }
   }
 }
@@ -66,7 +68,9 @@ template <typename T>
 static int run_add_noise(T* X, int64_t n, double sigma, uint64_t seed, uint64_t offset, double nan_fraction, hipStream_t st) {
   if (!X || n <= 0 || !(sigma >= 0.0) || !(nan_fraction >= 0.0) || nan_fraction > 1.0) { set_error("add_noise: bad argument"); return CMTFPLS_EINVAL; }
   const int64_t quads = (int64_t)(((offset + (uint64_t)n + 3) >> 2) - (offset >> 2));
-  hipLaunchKernelGGL((add_noise_kernel<T>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, X, n, sigma, seed, offset, nan_fraction);
+  int64_t blocks = (quads + 255) / 256;
+  if (blocks > 65536) blocks = 65536;                   // grid stride beyond (a launch is limited to < 2^32 threads)
+  hipLaunchKernelGGL((add_noise_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, X, n, quads, sigma, seed, offset, nan_fraction);
   return check_launch("add_noise");
 }
 

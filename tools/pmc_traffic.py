@@ -16,7 +16,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"contract_vec_kernel": 1, "score_kernel": 1, "deflate_kernel": 2, "deflate_rows_kernel": 2,
-           "deflate_contract_kernel": 2, "center_kernel": 2, "score_deflate_kernel": 2, "xcov_kernel": 1}
+           "deflate_contract_kernel": 2, "deflate_contract_rows_kernel": 2, "center_kernel": 2, "center_rows_kernel": 2,
+           "score_deflate_kernel": 2, "xcov_kernel": 1, "mttkrp_kernel": 1}
+ROUND = "r02"
 XBYTES = 65536 * 128 * 128 * 4
 
 
@@ -24,7 +26,7 @@ def one_pass(counter, outdir):
     os.makedirs(outdir, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "p", "--",
-           "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--graphs", "0"]
+           "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--graphs", "0", "--no-ceilings"]
     with open(os.path.join(outdir, "run.log"), "w") as log:
         subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT)
     return parse(counter, outdir)
@@ -65,7 +67,7 @@ def main():
             rec["algorithmic_bytes"] = passes * XBYTES
             rec["ratio"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes"]
         kernels[key] = rec
-    doc = {"method": __doc__.split("\n\n")[1].replace("\n", " "), "workload": "cfg2 65536x128x128 f32, 1 GPU",
+    doc = {"round": ROUND, "method": __doc__.split("\n\n")[1].replace("\n", " "), "workload": "cfg2 65536x128x128 f32, 1 GPU",
            "command": "python3 tools/pmc_traffic.py", "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps({k: round(v.get("ratio", 0), 4) for k, v in kernels.items()}))
