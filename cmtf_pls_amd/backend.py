@@ -314,6 +314,22 @@ class HipBackend:
         _lib.check(rc, "recon")
         return out
 
+    def recon_r2(self, X2: torch.Tensor, T: torch.Tensor, WA: torch.Tensor, WB: torch.Tensor, mean: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """[sum (xhat - x)^2, sum x^2] over the finite entries of x = X2 - mean: calcR2X's two sums (util.py:7-15) against
+        the never-materialised reconstruction; None when the shape has no device form."""
+        I, P = X2.shape
+        R = T.shape[1]
+        A, B = WA.shape[0], WB.shape[0]
+        assert X2.is_contiguous() and T.stride(1) == 1 and WA.is_contiguous() and WB.is_contiguous() and P == A * B
+        ws = self._workspace("recon_r2", self.lib.cmtfpls_recon_r2_workspace_bytes(I, P))
+        out = self.empty(2)
+        rc = self._fn("recon_r2", X2)(_ptr(X2), _ptr(T), I, T.stride(0), R, _ptr(WA), _ptr(WB), A, B, _ptr(mean), _ptr(out),
+                                     _ptr(ws), ws.numel(), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "recon_r2")
+        return out
+
     def loo_tpls(self, X2: torch.Tensor, Y: torch.Tensor, A: int, B: int, R: int, tol: float, max_iter: int,
                  max_ws_bytes: int = 4 << 30) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
         """Leave-one-out predictions of a tPLS model (validate.py:24-33), every fold a workgroup: returns

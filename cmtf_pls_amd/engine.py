@@ -266,6 +266,30 @@ class NipalsEngine:
                 return None
             return out.view((T.shape[0],) + tuple(blk.shape[1:]))
 
+    def r2x_literal(self, state: FitState, X: torch.Tensor, block: int = 0) -> Optional[float]:
+        """calcR2X(X - X_mean, factors_to_tensor(X_factors)) (util.py:7-15 as called at tpls.py:115-117) for the rows
+        X (device, storage type, UNCENTRED, same rows as state.T) in one read of X, the reconstruction never
+        materialised (cmtfpls_recon_r2_*).  None when the backend / shape has no device form."""
+        be = self.be
+        if not hasattr(be, "recon_r2"):
+            return None
+        blk = state.blocks[block]
+        with self.device_ctx():
+            R = state.n_components
+            loads = blk.loadings
+            if len(blk.shape) == 2:
+                WA, WB = be.empty(1, R), loads[0]
+                WA.fill_(1.0)
+            else:
+                WA, WB = loads[0], loads[1]
+                for L in loads[2:]:
+                    WB = be.khatri_rao(WB, L)
+            out = be.recon_r2(X.view(X.shape[0], -1), state.T, WA, WB, blk.mean)
+            if out is None:
+                return None
+            res, ssq = self.comm.allreduce(out).cpu().tolist()
+            return 1.0 - res / ssq
+
     def _project_one_pass(self, state: FitState, Xs: List[torch.Tensor], mixed: bool = False) -> Optional[torch.Tensor]:
         """All R scores from ONE read of every (already centred, NaN-free) block.
 

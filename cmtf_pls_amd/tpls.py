@@ -183,5 +183,17 @@ class tPLS(_EstimatorBase):
             return X_scores, self._y_scores(X_scores, Y)
         return X_scores
 
+    def R2X_literal(self, X):
+        """calcR2X(X - X_mean, factors_to_tensor(X_factors)) of the training X (util.py:7-15 as tpls.py:115-117 calls it)
+        in one read of X on the GPU; equals R2X[-1], which the fit obtains from the deflation sweep instead."""
+        eng = self._get_engine()
+        Xd = to_device_copy(X, self._state.blocks[0].dtype or torch.float64, eng.be.device, copy=False)
+        r2 = eng.r2x_literal(self._state, Xd, 0)
+        if r2 is None:
+            from .util import calcR2X, factors_to_tensor
+            Xh = X.cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X)
+            r2 = calcR2X(Xh - self.X_mean, factors_to_tensor(self.X_factors))
+        return r2
+
     def X_reconstructed(self, rows=None, device: bool = False):
         return self._reconstruct(0, self.X_factors, self.X_mean, rows, device)          # tpls.py:188-189

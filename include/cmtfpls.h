@@ -249,6 +249,16 @@ int cmtfpls_recon_f32(const double* T, int64_t I, int ldt, int R, const double* 
                       const double* mean, float* out, void* stream);
 int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
                       const double* mean, double* out, void* stream);
+/* recon_r2: the two sums of calcR2X(X - mean, factors_to_tensor(X_factors)) (util.py:7-15 as called at tpls.py:115-117,
+ * cmtf.py:132-134) in ONE read of the original X, the reconstruction never materialised:
+ *   out[0] = sum over finite x of (xhat - x)^2,  out[1] = sum over finite x of x^2,  x = X[i,c] - mean[c] (mean
+ * nullable), xhat as in recon;  R2X = 1 - out[0] / out[1].  (The fit itself gets R2X from the deflation sweep; this
+ * is the literal formula for callers of calcR2X and for checking that identity at full size.)  R <= 16. */
+size_t cmtfpls_recon_r2_workspace_bytes(int64_t I, int64_t P);
+int cmtfpls_recon_r2_f32(const float* X, const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB,
+                         int A, int B, const double* mean, double* out, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_recon_r2_f64(const double* X, const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB,
+                         int A, int B, const double* mean, double* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- leave-one-out refits, all folds in one launch: validate.get_q2y  (cmtf_pls/validate.py:7-37) ------------
  * For every fold i in [fold0, fold0 + nfolds): a complete tPLS fit (tpls.py:73-113; R components, tol, max_iter, the

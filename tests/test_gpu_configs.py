@@ -36,11 +36,11 @@ def test_cfg3_coupled_medium_vs_oracle(api, algorithm):
     m.fit([x, xm], y, max_iter=40)
     fit = O.fit_ctpls([x, xm], y, 3, max_iter=40)
     s = np.abs(fit.T).max()
-    assert_allclose(m.factor_T, fit.T, rtol=2e-5, atol=2e-5 * s)
-    assert_allclose(m.Y_factors[1], fit.Q, rtol=2e-5, atol=2e-5)
+    assert_allclose(m.factor_T, fit.T, rtol=1e-5, atol=1e-5 * s)
+    assert_allclose(m.Y_factors[1], fit.Q, rtol=1e-5, atol=1e-5)
     for b in range(2):
-        assert_allclose(m.R2Xs[b], fit.r2x[b], rtol=2e-5, atol=2e-6)
-    assert_allclose(m.R2Y, fit.r2y, rtol=2e-5, atol=2e-6)
+        assert_allclose(m.R2Xs[b], fit.r2x[b], rtol=1e-5, atol=1e-6)
+    assert_allclose(m.R2Y, fit.r2y, rtol=1e-5, atol=1e-6)
     assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
 
 
@@ -54,9 +54,9 @@ def test_cfg4_nan30_medium_vs_oracle(api, algorithm):
     fit = O.fit_tpls(x, y, 3, max_iter=40)
     s = np.abs(fit.T).max()
     assert m.X_hasMiss
-    assert_allclose(m.X_factors[0], fit.T, rtol=5e-5, atol=5e-5 * s)
-    assert_allclose(m.R2X, fit.r2x[0], rtol=5e-5, atol=5e-6)
-    assert_allclose(m.R2Y, fit.r2y, rtol=5e-5, atol=5e-6)
+    assert_allclose(m.X_factors[0], fit.T, rtol=1e-5, atol=1e-5 * s)
+    assert_allclose(m.R2X, fit.r2x[0], rtol=1e-5, atol=1e-6)
+    assert_allclose(m.R2Y, fit.r2y, rtol=1e-5, atol=1e-6)
     assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
 
 

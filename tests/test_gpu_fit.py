@@ -85,7 +85,7 @@ def test_tpls_f32_storage_golden(api, golden_dir):
     assert_allclose(m2.X_factors[0], m.X_factors[0], rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-7), ("float32", 2e-5)])
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-7), ("float32", 1e-5)])
 def test_tpls_nan30_golden(api, golden_dir, dtype, rtol):
     """missingvals path (BASELINE configs[3] in small): 30 % NaN."""
     g = np.load(os.path.join(golden_dir, "oracle_tpls_f32in_nan30.npz"))
@@ -104,7 +104,7 @@ def test_tpls_nan30_golden(api, golden_dir, dtype, rtol):
     assert_allclose(m.X_reconstructed()[miss], g["recon"][miss], rtol=100 * rtol, atol=100 * rtol)
 
 
-@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-7), ("float32", 2e-5)])
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-7), ("float32", 1e-5)])
 def test_ctpls_golden(api, golden_dir, dtype, rtol):
     """Coupled tensor + matrix block (BASELINE configs[2] in small)."""
     g = np.load(os.path.join(golden_dir, "oracle_ctpls_small.npz"))
@@ -235,7 +235,7 @@ def test_smoke_entry():
 
 
 @pytest.mark.parametrize("shape,dtype,rtol", [((20, 8, 6, 4), "float64", 1e-6), ((12, 5, 4, 3, 2), "float64", 1e-6),
-                                              ((20, 8, 6, 4), "float32", 5e-5)])
+                                              ((20, 8, 6, 4), "float32", 1e-5)])
 def test_tpls_higher_order(api, shape, dtype, rtol):
     """X of order 4 and 5 (the shapes of tests/test_tpls.py:132-155, tests/test_missingvals.py:52)."""
     rng = np.random.default_rng(7)
@@ -286,7 +286,7 @@ def test_xcov_algorithm_on_gpu(api, case):
     direct loop and as the oracle."""
     rng = np.random.default_rng(31)
     x, y, cp = O.import_synthetic((300, 12, 8), 5, 3, error=0.2, seed=8)
-    dtype, rtol = ("float32", 2e-5) if case == "f32" else ("float64", 1e-7)
+    dtype, rtol = ("float32", 1e-5) if case == "f32" else ("float64", 1e-7)
     if case == "f32":
         x, y = x.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64)
     if case == "nan":
@@ -349,7 +349,7 @@ def test_one_pass_projection_on_gpu(api, case):
     import torch
     from cmtf_pls_amd.tpls import to_device_copy
     rng = np.random.default_rng(41)
-    dtype, rtol = (torch.float32, 2e-5) if case.endswith("f32") else (torch.float64, 1e-8)
+    dtype, rtol = (torch.float32, 1e-5) if case.endswith("f32") else (torch.float64, 1e-8)
     if case == "coupled":
         Xs = [rng.random((40, 6, 5, 4)), rng.random((40, 7, 8)), rng.random((40, 9))]
         Y = rng.random((40, 4))

@@ -269,3 +269,23 @@ def test_loo_declines_shapes_outside_its_form():
     m3 = tPLS(2)
     m3.fit(x3, y3)
     assert loo_predictions(m3) is None and np.isfinite(get_q2y(m3))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("shape,nan", [((60, 12, 16), 0.0), ((50, 12, 16), 0.25), ((40, 24), 0.0), ((30, 6, 4, 8), 0.0)])
+def test_literal_r2x_on_device_equals_the_deflation_identity(shape, nan, dtype):
+    """calcR2X(X_c, factors_to_tensor(X_factors)) (util.py:7-15, tpls.py:115-117) through cmtfpls_recon_r2_* == the R2X the
+    fit books from the deflation sweep == the oracle's literal formula."""
+    from cmtf_pls_amd import tPLS
+    x, y, _ = O.import_synthetic(shape, 3, 3, error=0.2, seed=19)
+    if dtype == "float32":
+        x, y = x.astype(np.float32).astype(np.float64), y.astype(np.float32).astype(np.float64)
+    if nan:
+        x[np.random.default_rng(2).random(x.shape) < nan] = np.nan
+    m = tPLS(3, dtype=dtype)
+    m.fit(x, y, max_iter=40)
+    lit = m.R2X_literal(x)
+    tol = 1e-10 if dtype == "float64" else 2e-6
+    assert abs(lit - m.R2X[-1]) < tol
+    want = O.calc_r2x(x - np.nanmean(x, axis=0), O.cp_factors_to_tensor(m.X_factors))
+    assert abs(lit - want) < tol
