@@ -160,16 +160,19 @@ def measure_ceilings(be, timer, scratch, src, row_bytes):
     nbytes = scratch.numel() * scratch.element_size()
     res = {"buffer_GB": nbytes / 1e9, "variants": {}}
     best = {}
+    maps = {0: "flat", 1: "chunk", 2: "rowwg", 3: "colowner"}
     for op, passes in (("read", 1), ("rmw", 2), ("copy", 2)):
-        for rb in (0, row_bytes):
-            for blocks in (1024, 2048, 4096):
+        for mp, blocks_list in ((0, (2048, 4096)), (1, (1024, 4096)), (2, (256, 512)), (3, (256, 512, 1024))):
+            for blocks in blocks_list:
                 if op == "copy":
-                    fn = lambda: be.ceiling("copy", src, rb, blocks, dst=scratch)
+                    fn = lambda: be.ceiling("copy", src, row_bytes, blocks, dst=scratch, map=mp)
                 else:
-                    fn = lambda: be.ceiling(op, scratch, rb, blocks)
-                ms = timer.time_calls(fn, n=4, warm=2)          # an even number of rmw launches: data restored
+                    fn = lambda: be.ceiling(op, scratch, row_bytes, blocks, map=mp)
+                if not fn():                                    # this map does not take the shape
+                    continue
+                ms = timer.time_calls(fn, n=4, warm=1)          # an even number of rmw launches in all: data restored
                 gbps = passes * nbytes / ms / 1e6
-                res["variants"][f"{op}:{'rows' if rb else 'flat'}:{blocks}"] = round(gbps, 1)
+                res["variants"][f"{op}:{maps[mp]}:{blocks}"] = round(gbps, 1)
                 if gbps > best.get(op, 0.0):
                     best[op] = gbps
     res["read_GBps"], res["rmw_GBps"], res["copy_GBps"] = best["read"], best["rmw"], best["copy"]

@@ -78,9 +78,9 @@ SIGNATURES = {
     "cmtfpls_add_noise_f32": (c_int, [_P, c_int64, c_double, c_uint64, c_uint64, c_double, _P]),
     "cmtfpls_add_noise_f64": (c_int, [_P, c_int64, c_double, c_uint64, c_uint64, c_double, _P]),
     "cmtfpls_ceiling_max_blocks": (c_int, []),
-    "cmtfpls_ceiling_read": (c_int, [_P, c_size_t, c_int64, _P, c_int, _P]),
-    "cmtfpls_ceiling_rmw": (c_int, [_P, c_size_t, c_int64, c_int, _P]),
-    "cmtfpls_ceiling_copy": (c_int, [_P, _P, c_size_t, c_int64, c_int, _P]),
+    "cmtfpls_ceiling_read": (c_int, [_P, c_size_t, c_int64, c_int, _P, c_int, _P]),
+    "cmtfpls_ceiling_rmw": (c_int, [_P, c_size_t, c_int64, c_int, c_int, _P]),
+    "cmtfpls_ceiling_copy": (c_int, [_P, _P, c_size_t, c_int64, c_int, c_int, _P]),
 }
 
 _lib = None

@@ -61,20 +61,24 @@ class HipBackend:
 
     # -- measured HBM ceilings (bench.py: roofline denominators measured in the same run) ---------
     def ceiling(self, op: str, buf: torch.Tensor, row_bytes: int = 0, blocks: int = 2048,
-                dst: Optional[torch.Tensor] = None) -> None:
-        """op: "read" | "rmw" (negates in place; call an even number of times) | "copy" (needs dst)."""
+                dst: Optional[torch.Tensor] = None, map: int = 0) -> bool:
+        """op: "read" | "rmw" (negates in place; call an even number of times) | "copy" (needs dst); map: 0 flat,
+        1 chunked, 2 row per 1024-thread workgroup with a barrier, 3 column owner.  False when the map does not take the shape."""
         nbytes = buf.numel() * buf.element_size()
         if op == "read":
             sink = self._workspace("ceiling_sink", 4 * self.lib.cmtfpls_ceiling_max_blocks())
-            rc = self.lib.cmtfpls_ceiling_read(_ptr(buf), nbytes, int(row_bytes), _ptr(sink), int(blocks), self._stream())
+            rc = self.lib.cmtfpls_ceiling_read(_ptr(buf), nbytes, int(row_bytes), int(map), _ptr(sink), int(blocks), self._stream())
         elif op == "rmw":
-            rc = self.lib.cmtfpls_ceiling_rmw(_ptr(buf), nbytes, int(row_bytes), int(blocks), self._stream())
+            rc = self.lib.cmtfpls_ceiling_rmw(_ptr(buf), nbytes, int(row_bytes), int(map), int(blocks), self._stream())
         elif op == "copy":
             assert dst is not None and dst.numel() * dst.element_size() >= nbytes
-            rc = self.lib.cmtfpls_ceiling_copy(_ptr(buf), _ptr(dst), nbytes, int(row_bytes), int(blocks), self._stream())
+            rc = self.lib.cmtfpls_ceiling_copy(_ptr(buf), _ptr(dst), nbytes, int(row_bytes), int(map), int(blocks), self._stream())
         else:
             raise ValueError(op)
+        if rc == 4:
+            return False
         _lib.check(rc, "ceiling_" + op)
+        return True
 
     # -- preprocess: tpls.py:61-71 -----------------------------------------------------------
     def colstats(self, X2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -542,8 +542,18 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
     return CMTFPLS_EINVAL;
   }
   if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) { set_error("X must be 16-byte aligned"); return CMTFPLS_EINVAL; }
-  constexpr int U = (MODE == 2) ? 2 : kContractU;      // the statistics pass carries a second set of accumulators
-  const ContractPlan p = plan_contract(I, P, (int)sizeof(T), U);
+  // column groups per thread: 4 (wider tiles, half as many partial rows per column: +2.8 % at 65536 rows) when a
+  // workgroup still gets >= 128 rows, else 2 (shards of <= 16 K rows: 94 vs 101 us at 8192 x 128 x 128,
+  // profiles/r02g_tune_small.txt); the statistics pass carries a second set of accumulators and stays at 2
+  const bool wideU = MODE != 2 && kContractU == 4 && plan_contract(I, P, (int)sizeof(T), 4).rows_per_block >= 128;
+  const ContractPlan p = plan_contract(I, P, (int)sizeof(T), wideU ? 4 : 2);
+#define CV_LAUNCH(YQF, LDS, UPTR, YP, LDY, MM, QP)                                                                                   \
+  do {                                                                                                                               \
+    if (wideU) hipLaunchKernelGGL((contract_vec_kernel<T, MODE, YQF, (MODE == 2) ? 2 : 4>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR, \
+                                  part, cntpart, p.rows_per_block, YP, LDY, MM, QP);                                                  \
+    else hipLaunchKernelGGL((contract_vec_kernel<T, MODE, YQF, 2>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR, part, cntpart, \
+                            p.rows_per_block, YP, LDY, MM, QP);                                                                       \
+  } while (0)
   // Wide blocks (>= kYqUnfuseTiles column tiles): every column tile of a row block would repeat the same
   // u = Y q prologue, so u is formed once by the rowdot kernel into the tail of the workspace instead
   // (262144 x 256 x 256, M = 32: 2 % of the sweep)
@@ -561,8 +571,7 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
     double* u_ws = part + (size_t)p.row_blocks * P;
     const int rc = cmtfpls_rowdot_f64(Y, ldy, M, I, q, u_ws, nullptr, nullptr, nullptr, 0, st);
     if (rc != CMTFPLS_OK) return rc;
-    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false, U>), grid, dim3(kSweepThreads), 0, st, X, I, P, u_ws, part, cntpart,
-                       p.rows_per_block, nullptr, 0, 0, nullptr);
+    CV_LAUNCH(false, 0, u_ws, nullptr, 0, 0, nullptr);
   } else if (yq) {
     // supported: vector shape, M <= 64 (one Y row per wavefront pass)
     const size_t lds = (size_t)kYqChunk * sizeof(double);
@@ -574,19 +583,18 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
       hipLaunchKernelGGL((contract_narrow_kernel<T, MODE, true>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
                          p.rows_per_block, Y, ldy, M, q, ncv, RS);
     else
-      hipLaunchKernelGGL((contract_vec_kernel<T, MODE, true, U>), grid, dim3(kSweepThreads), lds, st, X, I, P, u, part, cntpart,
-                         p.rows_per_block, Y, ldy, M, q);
+      CV_LAUNCH(true, lds, u, Y, ldy, M, q);
   } else if (narrow) {
     hipLaunchKernelGGL((contract_narrow_kernel<T, MODE, false>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
                        p.rows_per_block, nullptr, 0, 0, nullptr, ncv, RS);
   } else if (p.vec) {
-    hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false, U>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart,
-                       p.rows_per_block, nullptr, 0, 0, nullptr);
+    CV_LAUNCH(false, 0, u, nullptr, 0, 0, nullptr);
   } else {
     hipLaunchKernelGGL((contract_scalar_kernel<T, MODE>), grid, dim3(kSweepThreads), 0, st, X, I, P, u, part, cntpart, p.rows_per_block);
   }
   launch_reduce_rows(part, p.row_blocks, P, out, st);
   if (MODE == 2) launch_reduce_rows(cntpart, p.row_blocks, P, cnt_out, st);
+#undef CV_LAUNCH
   return check_launch("mode0_contract");
 }
 

@@ -288,13 +288,18 @@ int cmtfpls_add_noise_f64(double* X, int64_t n, double sigma, uint64_t seed, uin
  * kernel"; not a reference call site) ---------------------------------------------------------------
  * Plain 16-byte-per-lane non-temporal streaming kernels over `bytes` of a 16-byte-aligned buffer:
  * read (sum kept in sink[0..blocks)), in-place read-modify-write (negates: two calls restore the data),
- * copy src -> dst.  row_bytes == 0: flat map (consecutive workgroups adjacent, grid stride); row_bytes > 0
- * (multiple of 16): a workgroup owns row_bytes contiguous bytes at a time, grid-striding over such rows
- * (the map of the row-wise sweeps).  blocks <= cmtfpls_ceiling_max_blocks() workgroups of 256 threads. */
+ * copy src -> dst, each under one of four workgroup -> address maps:
+ *   0 flat (consecutive workgroups adjacent, grid stride; row_bytes ignored),
+ *   1 chunked (a 256-thread workgroup owns row_bytes contiguous bytes at a time, grid stride over rows),
+ *   2 row per 1024-thread workgroup, barrier between the read burst and the write burst (row_bytes = 16 KB * {1,2,4,8}):
+ *     the map of deflate_rows / center_rows / score_deflate,
+ *   3 column owner: a 256-thread workgroup owns 8 KB of columns and a block of rows, 4 rows in flight (row_bytes a
+ *     multiple of 8 KB; `blocks` = total workgroups): the map of the contraction and of deflate_contract.
+ * blocks <= cmtfpls_ceiling_max_blocks(). */
 int cmtfpls_ceiling_max_blocks(void);
-int cmtfpls_ceiling_read(const void* buf, size_t bytes, int64_t row_bytes, float* sink, int blocks, void* stream);
-int cmtfpls_ceiling_rmw(void* buf, size_t bytes, int64_t row_bytes, int blocks, void* stream);
-int cmtfpls_ceiling_copy(const void* src, void* dst, size_t bytes, int64_t row_bytes, int blocks, void* stream);
+int cmtfpls_ceiling_read(const void* buf, size_t bytes, int64_t row_bytes, int map, float* sink, int blocks, void* stream);
+int cmtfpls_ceiling_rmw(void* buf, size_t bytes, int64_t row_bytes, int map, int blocks, void* stream);
+int cmtfpls_ceiling_copy(const void* src, void* dst, size_t bytes, int64_t row_bytes, int map, int blocks, void* stream);
 
 #ifdef __cplusplus
 }

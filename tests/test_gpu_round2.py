@@ -78,17 +78,19 @@ def test_ceiling_kernels_move_the_bytes():
     from cmtf_pls_amd.backend import HipBackend
     be = HipBackend("cuda:0")
     n = 1 << 22
-    a = torch.arange(n, dtype=torch.float32, device="cuda:0")
+    ref = torch.arange(n, dtype=torch.float32, device="cuda:0")
+    a = ref.clone()
     b = torch.zeros_like(a)
-    for rb in (0, 4096):
-        be.ceiling("copy", a, rb, 512, dst=b)
+    for mp, rb in ((0, 0), (1, 4096), (2, 16384), (2, 65536), (3, 8192), (3, 65536)):
+        assert be.ceiling("copy", a, rb, 512, dst=b, map=mp)
         assert torch.equal(a, b)
         b.zero_()
-        be.ceiling("rmw", a, rb, 512)
-        assert torch.equal(a, -torch.arange(n, dtype=torch.float32, device="cuda:0"))
-        be.ceiling("rmw", a, rb, 512)
-        assert torch.equal(a, torch.arange(n, dtype=torch.float32, device="cuda:0"))
-        be.ceiling("read", a, rb, 512)
+        assert be.ceiling("rmw", a, rb, 512, map=mp)
+        assert torch.equal(a, -ref)
+        assert be.ceiling("rmw", a, rb, 512, map=mp)
+        assert torch.equal(a, ref)
+        assert be.ceiling("read", a, rb, 512, map=mp)
+    assert not be.ceiling("read", a, 16384 * 16, 512, map=2)       # a map that does not take the row length declines
     torch.cuda.synchronize()
 
 

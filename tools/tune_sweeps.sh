@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "u4cb1024:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1024" "u4cb1536:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1536" "u4cb2048:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=2048" "u4cb1024r2:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1024 -DCMTFPLS_UNROLL=2" "u4cb1024b:-DCMTFPLS_CONTRACT_U=4 -DCMTFPLS_CONTRACT_BLOCKS=1024" "base2:" "dcold:-DCMTFPLS_DC_ROWS=0")
+VARIANTS=("base:" "u2cb1024:-DCMTFPLS_CONTRACT_U=2" "u4cb512:-DCMTFPLS_CONTRACT_BLOCKS=512" "u2cb512:-DCMTFPLS_CONTRACT_U=2 -DCMTFPLS_CONTRACT_BLOCKS=512" "u4cb256:-DCMTFPLS_CONTRACT_BLOCKS=256" "u2cb2048:-DCMTFPLS_CONTRACT_U=2 -DCMTFPLS_CONTRACT_BLOCKS=2048")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
