@@ -380,7 +380,10 @@ def test_xcov_identities_and_quadform(be):
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 @pytest.mark.parametrize("shape,R", [((37, 10, 8), 3), ((100, 38, 65), 8), ((64, 1, 20), 5), ((33, 1, 7), 2),
-                                     ((50, 128, 128), 10), ((29, 5, 4), 16), ((70, 12, 8), 17), ((300, 16, 16), 32)])
+                                     ((50, 128, 128), 10), ((29, 5, 4), 16), ((70, 12, 8), 17), ((300, 16, 16), 32),
+                                     # I % 16 == 0 and 512-byte multiples of columns: the coalesced LDS-tile form (1 and 2 component tiles,
+                                     # several chunks per row, a matrix block, KronWalk carries)
+                                     ((64, 128, 128), 10), ((48, 16, 16), 20), ((32, 1, 512), 3), ((80, 24, 16), 16), ((16, 256, 256), 10)])
 def test_mttkrp_mfma(be, shape, R, dt):
     """M = X_(0) (WA (.) WB) on the f64 matrix cores, Khatri-Rao operand formed in LDS, against NumPy
     (asymmetric random data: checks the A/B/D lane maps; ragged rows, odd B, 1 and 2 component tiles)."""

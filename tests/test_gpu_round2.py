@@ -13,7 +13,7 @@ import oracle as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--shape", "2048", "128", "128", "--steps", "4", "--warmup", "2", "--no-cpu", "--no-fit", "--no-ceilings"]
+SMALL = ["--shape", "2048", "128", "128", "--steps", "4", "--warmup", "2", "--no-cpu", "--no-ceilings"]      # incl. the fit legs
 
 
 def _bench(extra_args, extra_env):
@@ -36,6 +36,9 @@ def test_bench_single_rank_rccl_collectives():
     assert c["backend"] == "nccl" and c["forced_single_rank"] and abs(c["collectives_per_step"] - 2.0) < 1e-9
     assert str(128 * 128 * 8) in c["allreduce_ms_by_bytes"] and str(16 * 8) in c["allreduce_ms_by_bytes"]
     assert out["value"] > 0 and out["config"]["hip_graphs"]
+    # the sharded fit legs ran over RCCL too (normal equations / S / norms all-reduced) and agree with each other
+    assert len(out["fit"]["n_iter"]) == 10 and out["fit"]["xcov"]["n_iter"] == out["fit"]["n_iter"]
+    assert out["fit"]["xcov"]["max_abs_dT_vs_direct"] < 1e-5
 
 
 def test_bench_launches_two_ranks_by_itself():
@@ -45,6 +48,7 @@ def test_bench_launches_two_ranks_by_itself():
     assert out["n_gpus"] == 2 and out["config"]["rows_per_gpu"] == 1024
     assert out["collectives"]["ranks"] == 2 and out["collectives"]["backend"] == "gloo"
     assert out["config"]["rccl_ranks"] == 0            # gloo rehearsal: no RCCL ranks claimed
+    assert len(out["fit"]["n_iter"]) == 10 and out["fit"]["xcov"]["n_iter"] == out["fit"]["n_iter"]
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

@@ -70,6 +70,46 @@ __global__ __launch_bounds__(THREADS) void col_kernel(f4* __restrict__ p, int64_
   if (!WRITE && acc == 123.456f) sink[blockIdx.x] = acc;
 }
 
+// the MTTKRP's A-operand access: a wavefront owns 16 rows; lane (ri = l & 15, kq = l >> 4) loads 16 B at
+// row ri, column c0 + 16 s + 4 kq: one load instruction touches 16 rows x 64 B
+template <int UN>
+__global__ __launch_bounds__(256) void mfma_rows_kernel(const f4* __restrict__ p, int64_t nrows, int64_t rowvec, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ri = lane & 15, kq = lane >> 4;
+  float acc = 0.f;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < nrows / 16; grp += (int64_t)gridDim.x * 4) {
+    const f4* __restrict__ row = p + (grp * 16 + ri) * rowvec;
+    for (int64_t c0 = 0; c0 < rowvec; c0 += 4 * UN) {
+      f4 v[UN];
+#pragma unroll
+      for (int s = 0; s < UN; ++s) v[s] = __builtin_nontemporal_load(row + c0 + 4 * s + kq);
+#pragma unroll
+      for (int s = 0; s < UN; ++s) acc += (v[s].x + v[s].y) + (v[s].z + v[s].w);
+    }
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+}
+
+// the same bytes fetched row-contiguously: lane l loads 16 B at row q, column c0 + l (one instruction = 1 KB of one row)
+template <int UN>
+__global__ __launch_bounds__(256) void mfma_rows_coalesced_kernel(const f4* __restrict__ p, int64_t nrows, int64_t rowvec, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < nrows / 16; grp += (int64_t)gridDim.x * 4) {
+    const f4* __restrict__ base = p + grp * 16 * rowvec;
+    for (int64_t c0 = 0; c0 < rowvec; c0 += 64) {
+#pragma unroll
+      for (int q0 = 0; q0 < 16; q0 += UN) {
+        f4 v[UN];
+#pragma unroll
+        for (int s = 0; s < UN; ++s) v[s] = __builtin_nontemporal_load(base + (q0 + s) * rowvec + c0 + lane);
+#pragma unroll
+        for (int s = 0; s < UN; ++s) acc += (v[s].x + v[s].y) + (v[s].z + v[s].w);
+      }
+    }
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+}
+
 extern "C" int exp_launch(int kind, void* buf, int64_t nrows, int64_t rowvec, int grid, int lds_pad, float* sink, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   f4* p = (f4*)buf;
@@ -110,6 +150,10 @@ extern "C" int exp_launch(int kind, void* buf, int64_t nrows, int64_t rowvec, in
                hipLaunchKernelGGL((col_kernel<1024, 4, 2, false>), dim3(ct, rb), dim3(1024), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
     case 37: { int ct = (int)(rowvec / (1024 * 4)); int rb = grid / ct; int rpb = (int)((nrows + rb - 1) / rb);
                hipLaunchKernelGGL((col_kernel<1024, 4, 4, false>), dim3(ct, rb), dim3(1024), lds_pad, st, p, nrows, rowvec, rpb, sink); } break;
+    case 40: hipLaunchKernelGGL((mfma_rows_kernel<4>), dim3(grid), dim3(256), lds_pad, st, p, nrows, rowvec, sink); break;
+    case 41: hipLaunchKernelGGL((mfma_rows_kernel<8>), dim3(grid), dim3(256), lds_pad, st, p, nrows, rowvec, sink); break;
+    case 42: hipLaunchKernelGGL((mfma_rows_coalesced_kernel<4>), dim3(grid), dim3(256), lds_pad, st, p, nrows, rowvec, sink); break;
+    case 43: hipLaunchKernelGGL((mfma_rows_coalesced_kernel<8>), dim3(grid), dim3(256), lds_pad, st, p, nrows, rowvec, sink); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 3;
