@@ -15,6 +15,14 @@
 //   B operand of MFMA e = W[c0 + 4*kq + e][r = l & 15] = sA[j][r] * sB[k][r]   (B[k = l>>4][j = l&15])
 //   all four MFMAs accumulate into the same D: D[(l>>4) + 4*g][l & 15] = M[i0 + (l>>4) + 4*g][r].
 // One wavefront owns 16 whole rows (no partials, fixed summation order).
+//
+// Round-2 negative results (kept out of the code): (1) the operand layout makes every load instruction touch
+// 16 rows x 64 B, a pattern that by itself tops out at 6.0 TB/s against 7.0-7.2 TB/s for row-contiguous reads
+// (tools/exp/rowexp.hip kinds 40-43, profiles/r02i_mfma_access.txt); a variant that fetched 16 x 128-column tiles
+// row-contiguously and transposed them through a wavefront-private LDS tile ran at the SAME 0.85-0.87 ms;
+// (2) so did four independent accumulator chains instead of one.  The kernel is bound by the f64 matrix pipe on the
+// 16-wide tile that R = 10 components occupy (1.68e7 MFMAs of 64 cycles = 0.44 ms at 2.4 GHz, more at the clock the
+// chip holds under f64 MFMA load), not by its reads (profiles/r02k_mttkrp_variants.txt).
 #include "common.hpp"
 
 namespace cmtfpls {
@@ -94,83 +102,6 @@ __global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, in
 }
 
 
-// The same product with COALESCED reads of X (round 2).  The MFMA operand layout puts the 16 rows of a tile on
-// the low lane bits, so loading operands directly makes every load instruction touch 16 rows x 64 B -- a pattern
-// that by itself tops out at 6.0 TB/s against 7.0-7.2 TB/s for row-contiguous reads (tools/exp/rowexp.hip kinds
-// 40-43, profiles/r02i_mfma_access.txt).  Here a wavefront fetches its 16 x CW tile row-contiguously (one load
-// instruction = 2 rows x 512 B), parks it in a wavefront-private LDS tile and reads it back in the MFMA layout
-// (ds_read_b128, rows padded by one vector: conflict-free); the loads of the next chunk are in flight while the
-// MFMAs of the current one run.  No workgroup barrier: a wavefront's LDS operations complete in order.
-// The loading rows are padded to 16 RT + 4 doubles so that the four k-slots of a wavefront (rows k, k+V, k+2V, k+3V
-// of sB) fall on two 128-byte bank halves instead of one (2 LDS passes instead of 4 per operand read).
-// Needs I % 16 == 0, P % (32 V) == 0, B % V == 0; same arithmetic and summation order over columns as mttkrp_kernel.
-template <typename T, int RT>
-__global__ __launch_bounds__(256) void mttkrp_tile_kernel(const T* __restrict__ X, int64_t I, int A, int B,
-                                                         const double* __restrict__ WA, const double* __restrict__ WB, int R,
-                                                         double* __restrict__ out, int ldo) {
-  constexpr int V = 16 / (int)sizeof(T);     // elements per 16-byte vector
-  constexpr int NVC = 32;                    // vectors per row per chunk (512 B)
-  constexpr int CW = NVC * V;                // columns per chunk
-  constexpr int RSV = NVC + 1;               // tile row stride in vectors
-  constexpr int WS = 16 * RT + 4;            // loading row stride in doubles
-  using VT = Pack<T, V>;
-  extern __shared__ double lds[];
-  double* sA = lds;
-  double* sB = lds + (size_t)A * WS;
-  VT* tiles = reinterpret_cast<VT*>(sB + (size_t)B * WS);
-  for (int idx = threadIdx.x; idx < A * WS; idx += 256) { const int j = idx / WS, r = idx % WS; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
-  for (int idx = threadIdx.x; idx < B * WS; idx += 256) { const int k = idx / WS, r = idx % WS; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ri = lane & 15, kq = lane >> 4;
-  const int lrow = lane >> 5, lvec = lane & 31;          // load map: 2 rows x 32 vectors per instruction
-  VT* tile = tiles + (size_t)wv * 16 * RSV;
-  const int64_t P = (int64_t)A * B;
-  const int64_t ngroups = I / 16;
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
-    const T* __restrict__ xb = X + grp * 16 * P + (int64_t)lrow * P + (int64_t)lvec * V;
-    VT g[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) g[s] = ld_stream(reinterpret_cast<const VT*>(xb + (int64_t)(2 * s) * P));
-    d4m_t acc[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t] = d4m_t{0.0, 0.0, 0.0, 0.0};
-    KronWalk w(V * kq, 4 * V, B);
-    for (int64_t c0 = 0; c0 < P; c0 += CW) {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) tile[(2 * s + lrow) * RSV + lvec] = g[s];
-      if (c0 + CW < P) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) g[s] = ld_stream(reinterpret_cast<const VT*>(xb + (int64_t)(2 * s) * P + c0 + CW));
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int ss = 0; ss < NVC / 4; ++ss) {
-        const VT x = tile[ri * RSV + 4 * ss + kq];
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const double a = (double)x.e[e];
-#pragma unroll
-          for (int t = 0; t < RT; ++t) {
-            const double b = sA[(size_t)w.j * WS + t * 16 + ri] * sB[(size_t)(w.k + e) * WS + t * 16 + ri];
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-          }
-        }
-        w.next();
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int64_t row = grp * 16 + kq + 4 * gq;
-        const int r = t * 16 + ri;
-        if (r < R) out[row * ldo + r] = acc[t][gq];
-      }
-  }
-}
-
 template <typename T>
 static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, const double* WB, int R, double* out, int ldo,
                       hipStream_t st) {
@@ -184,20 +115,6 @@ static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, con
   int grid = (int)((ngroups + 3) / 4);
   if (grid > 2048) grid = 2048;
   const dim3 g(grid), b(256);
-#ifndef CMTFPLS_MTTKRP_TILE
-#define CMTFPLS_MTTKRP_TILE 1
-#endif
-  {
-    // coalesced form: row-contiguous loads staged through a wavefront-private LDS tile
-    constexpr int V = 16 / (int)sizeof(T);
-    const size_t lds_t = (size_t)(A + B) * (16 * rt + 4) * sizeof(double) + (size_t)4 * 16 * 33 * 16;
-    if (CMTFPLS_MTTKRP_TILE && (B % V) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (I % 16) == 0 &&
-        (((int64_t)A * B) % (32 * V)) == 0 && lds_t <= 150 * 1024) {
-      if (rt == 1) hipLaunchKernelGGL((mttkrp_tile_kernel<T, 1>), g, b, lds_t, st, X, I, A, B, WA, WB, R, out, ldo);
-      else hipLaunchKernelGGL((mttkrp_tile_kernel<T, 2>), g, b, lds_t, st, X, I, A, B, WA, WB, R, out, ldo);
-      return check_launch("mttkrp");
-    }
-  }
   const bool fast = vec && (I % 16 == 0) && (((int64_t)A * B) % (16 * CMTFPLS_MTTKRP_UN) == 0);
 #define ML(VC, RTT, FS) hipLaunchKernelGGL((mttkrp_kernel<T, VC, RTT, FS>), g, b, lds, st, X, I, A, B, WA, WB, R, out, ldo)
   if (fast) { if (rt == 1) ML(true, 1, true); else ML(true, 2, true); }
