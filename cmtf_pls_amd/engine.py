@@ -241,6 +241,21 @@ class NipalsEngine:
             scores[:, a].copy_(t)
         return scores
 
+    def _kr_operands(self, blk: BlockState, R: int):
+        """(WA, WB): the block's loading matrices as the factored Khatri-Rao operand the matrix kernels take,
+        W[c, r] = WA[c / B, r] * WB[c % B, r] (a matrix block: WA = ones; order >= 4: WB = column-wise Kronecker
+        product of the trailing modes' loadings, formed on the device)."""
+        be = self.be
+        loads = blk.loadings
+        if len(blk.shape) == 2:
+            WA = be.empty(1, R)
+            WA.fill_(1.0)
+            return WA, loads[0]
+        WB = loads[1]
+        for L in loads[2:]:
+            WB = be.khatri_rao(WB, L)
+        return loads[0], WB
+
     def reconstruct(self, state: FitState, block: int = 0, rows: Optional[slice] = None) -> Optional[torch.Tensor]:
         """Rows of factors_to_tensor(X_factors) + X_mean (util.py:18-20 with tpls.py:188-189 / cmtf.py:233-237) for
         one block, formed on the GPU in the block's storage type: Xhat = T (W_1 (.) W_2 (.) ...)^T + mean with the
@@ -252,15 +267,7 @@ class NipalsEngine:
         blk = state.blocks[block]
         with self.device_ctx():
             T = state.T if rows is None else state.T[rows]
-            R = state.n_components
-            loads = blk.loadings
-            if len(blk.shape) == 2:
-                WA, WB = be.empty(1, R), loads[0]
-                WA.fill_(1.0)
-            else:
-                WA, WB = loads[0], loads[1]
-                for L in loads[2:]:
-                    WB = be.khatri_rao(WB, L)
+            WA, WB = self._kr_operands(blk, state.n_components)
             out = be.empty(T.shape[0], blk.A * blk.B, dtype=blk.dtype or torch.float64)
             if T.shape[0] == 0 or be.recon(T, WA, WB, blk.mean, out) is None:
                 return None
@@ -275,15 +282,7 @@ class NipalsEngine:
             return None
         blk = state.blocks[block]
         with self.device_ctx():
-            R = state.n_components
-            loads = blk.loadings
-            if len(blk.shape) == 2:
-                WA, WB = be.empty(1, R), loads[0]
-                WA.fill_(1.0)
-            else:
-                WA, WB = loads[0], loads[1]
-                for L in loads[2:]:
-                    WB = be.khatri_rao(WB, L)
+            WA, WB = self._kr_operands(blk, state.n_components)
             out = be.recon_r2(X.view(X.shape[0], -1), state.T, WA, WB, blk.mean)
             if out is None:
                 return None
@@ -308,13 +307,7 @@ class NipalsEngine:
         Gs = be.empty(nb, R * R)
         for b, (blk, X) in enumerate(zip(state.blocks, Xs)):
             loads = blk.loadings
-            if len(blk.shape) == 2:
-                WA, WB = be.empty(1, R), loads[0]
-                WA.fill_(1.0)
-            else:
-                WA, WB = loads[0], loads[1]
-                for L in loads[2:]:                       # column-wise Kronecker of the remaining modes
-                    WB = be.khatri_rao(WB, L)
+            WA, WB = self._kr_operands(blk, R)
             if be.mttkrp(X.view(I, -1), blk.A, blk.B, WA, WB, Ms[b].view(I, R), mixed=mixed) is None:
                 return None
             for m, L in enumerate(loads):                 # Gram of a Khatri-Rao product = Hadamard product of the mode Grams
