@@ -1062,6 +1062,125 @@ __global__ __launch_bounds__(MAXT) void score_deflate_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// short rows (P <= 64 * V * 4 elements, e.g. the I x 512 matrix block of a coupled fit, small tensors):
+// a wavefront owns RB = 8 / NVL WHOLE rows at a time
+// ------------------------------------------------------------------------------------------
+// With one row per wavefront a short row keeps only NVL (1-2) 16-byte loads per lane in flight: 2.2-2.7 TB/s at
+// 65536 x 512.  Here a wavefront issues the loads of RB consecutive rows (8 per lane in all) before it touches any
+// of them; every lane keeps the loadings of ITS columns in registers (no LDS, no index walk), the row sums are
+// butterfly wave sums, and the rows never leave the registers between score and deflation (no workgroup barrier).
+// OP 0: score (GRAM: + partial sums of Y^T t)   1: deflate with the given t   2: score, then deflate with it.
+// Per lane the arithmetic and the column assignment (c = lane * V + n * 64 * V) are those of score_kernel /
+// deflate_kernel, bit for bit.
+template <typename T, bool MASKED, bool GRAM, int NVL, int OP>
+__global__ __launch_bounds__(kSweepThreads) void rows_narrow_kernel(
+    T* __restrict__ X, int64_t I, int A, int B, const double* __restrict__ wA, const double* __restrict__ wB,
+    const double* __restrict__ rowcnt, double* __restrict__ t, const double* __restrict__ Y, int ldy, int M,
+    double* __restrict__ qpart, double* __restrict__ ssq_part) {
+  __shared__ double qs[kSweepThreads / kWave][kWave];
+  __shared__ double red[16];
+  constexpr int V = VecOf<T>::N;
+  constexpr int RB = 8 / NVL;
+  using VT = Pack<T, V>;
+  const int lane = threadIdx.x & 63;
+  const int P = A * B;
+  double wa[NVL], wb[NVL][V];
+  bool ok[NVL];
+#pragma unroll
+  for (int n = 0; n < NVL; ++n) {
+    const int c = lane * V + n * 64 * V;
+    ok[n] = c < P;
+    const int cs = ok[n] ? c : 0;
+    wa[n] = wA[cs / B];                                  // B % V == 0: one j for the whole vector
+#pragma unroll
+    for (int e = 0; e < V; ++e) wb[n][e] = wB[cs % B + e];
+  }
+  const int64_t nwaves = (int64_t)gridDim.x * (kSweepThreads / kWave);
+  double qacc = 0.0, ssq = 0.0;
+  for (int64_t row0 = ((int64_t)blockIdx.x * (kSweepThreads / kWave) + (threadIdx.x >> 6)) * RB; row0 < I; row0 += nwaves * RB) {
+    VT x[RB][NVL];
+    double yv[RB], tin[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int64_t row = (row0 + r < I) ? row0 + r : I - 1;          // clamped: no branch around the loads
+#pragma unroll
+      for (int n = 0; n < NVL; ++n) x[r][n] = ld_stream(reinterpret_cast<const VT*>(X + row * P + (ok[n] ? lane * V + n * 64 * V : 0)));
+      if (GRAM) yv[r] = Y[row * ldy + ((lane < M) ? lane : 0)];
+      if (OP == 1) tin[r] = t[row];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const bool live = row0 + r < I;                                 // uniform across the wavefront
+      double ti = (OP == 1) ? tin[r] : 0.0;
+      if (OP != 1) {
+        double acc = 0.0;
+#pragma unroll
+        for (int n = 0; n < NVL; ++n)
+          if (ok[n]) acc = fma(wa[n], dot_pack<T, V, MASKED>(x[r][n], wb[n]), acc);
+        acc = wave_sum(acc);                                          // identical bits in every lane
+        ti = MASKED ? acc / rowcnt[live ? row0 + r : I - 1] * (double)P : acc;
+        if (live && lane == 0) t[row0 + r] = ti;
+        if (GRAM && live) qacc = fma(ti, yv[r], qacc);
+      }
+      if (OP != 0 && live) {
+#pragma unroll
+        for (int n = 0; n < NVL; ++n)
+          if (ok[n]) {
+            const double tw = ti * wa[n];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const T nv = (T)fma(-tw, wb[n][e], (double)x[r][n].e[e]);
+              x[r][n].e[e] = nv;
+              const double d = (nv == nv) ? (double)nv : 0.0;        // NaN (missing) stays NaN, skipped in the norm
+              ssq = fma(d, d, ssq);
+            }
+            st_stream(reinterpret_cast<VT*>(X + (row0 + r) * P + lane * V + n * 64 * V), x[r][n]);
+          }
+      }
+    }
+  }
+  if (GRAM) {
+    qs[threadIdx.x >> 6][lane] = qacc;
+    __syncthreads();
+    if (threadIdx.x < M) {
+      double tot = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < kSweepThreads / kWave; ++wv) tot += qs[wv][threadIdx.x];
+      qpart[(int64_t)blockIdx.x * M + threadIdx.x] = tot;
+    }
+  }
+  if (OP != 0 && ssq_part) {
+    const double sblk = block_sum(ssq, red);
+    if (threadIdx.x == 0) ssq_part[blockIdx.x] = sblk;
+  }
+}
+
+// vectors per lane per row of the short-row form (0: the row is too long or the shape is not a vector shape)
+template <typename T>
+static int narrow_nvl(const T* X, int A, int B) {
+#ifndef CMTFPLS_ROWS_NARROW
+#define CMTFPLS_ROWS_NARROW 1
+#endif
+  constexpr int V = VecOf<T>::N;
+  if (!CMTFPLS_ROWS_NARROW || (B % V) != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0) return 0;
+  const int64_t P = (int64_t)A * B;
+  if (P <= 64 * V) return 1;
+  if (P <= 2 * 64 * V) return 2;
+  if (P <= 4 * 64 * V) return 4;
+  return 0;
+}
+
+template <typename T, bool MASKED, bool GRAM, int OP>
+static void launch_rows_narrow(int nvl, hipStream_t st, T* X, int64_t I, int A, int B, const double* wA, const double* wB,
+                               const double* rowcnt, double* t, const double* Y, int ldy, int M, double* qpart, double* ssq_part) {
+  const dim3 g(kSweepBlocks), b(kSweepThreads);
+  if (nvl == 1) hipLaunchKernelGGL((rows_narrow_kernel<T, MASKED, GRAM, 1, OP>), g, b, 0, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart, ssq_part);
+  else if (nvl == 2) hipLaunchKernelGGL((rows_narrow_kernel<T, MASKED, GRAM, 2, OP>), g, b, 0, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart, ssq_part);
+  else hipLaunchKernelGGL((rows_narrow_kernel<T, MASKED, GRAM, 4, OP>), g, b, 0, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart, ssq_part);
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
@@ -1081,6 +1200,15 @@ static int run_score(const T* X, int64_t I, int A, int B, const double* wA, cons
   const bool gram = Y != nullptr;
   if (gram && (!qpart || M <= 0 || ldy < M)) { set_error("score_gram: bad argument"); return CMTFPLS_EINVAL; }
   if (gram && M > kWave) { set_error("score_gram: more than 64 responses; use score + gram_tn"); return CMTFPLS_EUNSUPPORTED; }
+  if (const int nvl = narrow_nvl(X, A, B)) {            // short rows: a wavefront owns several whole rows at a time
+    T* Xm = const_cast<T*>(X);                           // OP 0 does not write X
+    const bool msk = rowcnt != nullptr;
+    if (gram) { if (msk) launch_rows_narrow<T, true, true, 0>(nvl, st, Xm, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart, nullptr);
+                else launch_rows_narrow<T, false, true, 0>(nvl, st, Xm, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart, nullptr); }
+    else      { if (msk) launch_rows_narrow<T, true, false, 0>(nvl, st, Xm, I, A, B, wA, wB, rowcnt, t, nullptr, 0, 0, nullptr, nullptr);
+                else launch_rows_narrow<T, false, false, 0>(nvl, st, Xm, I, A, B, wA, wB, rowcnt, t, nullptr, 0, 0, nullptr, nullptr); }
+    return check_launch("score");
+  }
   size_t lds = loadings_lds_bytes(A, B);
   const bool gl = lds > kMaxLoadingsLds;               // loadings longer than the LDS: read them through L2
   if (gl) lds = 0;
@@ -1098,6 +1226,10 @@ template <typename T>
 static int run_deflate(T* X, int64_t I, int A, int B, const double* t, const double* wA, const double* wB,
                        double* ssq_part, hipStream_t st) {
   if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("deflate: bad argument"); return CMTFPLS_EINVAL; }
+  if (const int nvl = narrow_nvl(X, A, B)) {            // short rows: a wavefront owns several whole rows at a time
+    launch_rows_narrow<T, false, false, 1>(nvl, st, X, I, A, B, wA, wB, nullptr, const_cast<double*>(t), nullptr, 0, 0, nullptr, ssq_part);
+    return check_launch("deflate");
+  }
   const size_t lds = loadings_lds_bytes(A, B);
   const dim3 g(kSweepBlocks), b(kSweepThreads);
   if (lds > kMaxLoadingsLds) {                         // loadings longer than the LDS: read them through L2
@@ -1249,6 +1381,11 @@ template <typename T>
 static int run_score_deflate(T* X, int64_t I, int A, int B, const double* wA, const double* wB,
                              const double* rowcnt, double* t, double* ssq_part, hipStream_t st) {
   if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("score_deflate: bad argument"); return CMTFPLS_EINVAL; }
+  if (const int nvl = narrow_nvl(X, A, B)) {            // short rows: the rows stay in registers, no workgroup barrier
+    if (rowcnt) launch_rows_narrow<T, true, false, 2>(nvl, st, X, I, A, B, wA, wB, rowcnt, t, nullptr, 0, 0, nullptr, ssq_part);
+    else launch_rows_narrow<T, false, false, 2>(nvl, st, X, I, A, B, wA, wB, rowcnt, t, nullptr, 0, 0, nullptr, ssq_part);
+    return check_launch("score_deflate");
+  }
   const size_t lds = loadings_lds_bytes(A, B);
   if (lds > kMaxLoadingsLds) { set_error("score_deflate: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
   const bool v = vec_ok(X, B), m = rowcnt != nullptr;
