@@ -20,9 +20,12 @@
 // 16 rows x 64 B, a pattern that by itself tops out at 6.0 TB/s against 7.0-7.2 TB/s for row-contiguous reads
 // (tools/exp/rowexp.hip kinds 40-43, profiles/r02i_mfma_access.txt); a variant that fetched 16 x 128-column tiles
 // row-contiguously and transposed them through a wavefront-private LDS tile ran at the SAME 0.85-0.87 ms;
-// (2) so did four independent accumulator chains instead of one.  The kernel is bound by the f64 matrix pipe on the
-// 16-wide tile that R = 10 components occupy (1.68e7 MFMAs of 64 cycles = 0.44 ms at 2.4 GHz, more at the clock the
-// chip holds under f64 MFMA load), not by its reads (profiles/r02k_mttkrp_variants.txt).
+// (2) so did four independent accumulator chains instead of one (profiles/r02k_mttkrp_variants.txt); (3) with the
+// Khatri-Rao operand replaced by a constant AND the f32 -> f64 conversion removed -- loads and MFMAs only -- the
+// kernel still takes 0.77 ms (tools/exp/mttkrp_exp.hip, profiles/r02n_mttkrp_what_bounds_it.txt): 1.68e7 MFMAs on the
+// 16-wide tile that R = 10 components occupy cost ~47 ns each per SIMD at the clock the chip holds under f64 MFMA
+// load.  The LDS weight path adds 0.1 ms on top; sharing one B operand between two row groups recovers half of
+// that (0.82 ms) and was not worth a second kernel form.
 #include "common.hpp"
 
 namespace cmtfpls {
