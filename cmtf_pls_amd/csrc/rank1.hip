@@ -7,7 +7,7 @@
 // that stage their two 16-row panels in LDS with all loads in flight at once.  Scaling between
 // squarings is by an exact power of two taken from the trace, so the iteration is
 // bit-reproducible; it stops early (later launches return at once) when tr(G^2) == tr(G)^2 to
-// 1e-13.  The dominant column of the final G then seeds one exact pass y = M^T seed, x = M y with
+// 1e-13.  The dominant column of the final G then seeds one exact pass y = M^T seed, x = M y (= G_0 seed) with
 // Z itself (M = Z or Z^T), which also gives exact zeros in the loadings wherever Z has an all-zero
 // row or column (tests/test_tpls.py:98-104 relies on that).
 #include "common.hpp"
@@ -62,7 +62,7 @@ typedef double d4r_t __attribute__((ext_vector_type(4)));
 // have detected it.  In both cases the dominant column still goes through one exact pass with Z afterwards.
 __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* __restrict__ M, int n, int k, int ld,
                                                                 double* __restrict__ C, Rank1Ctl* __restrict__ ctl,
-                                                                int step, int out_buf) {
+                                                                int step, int out_buf, double* __restrict__ C_keep) {
   __shared__ double red[4][kTile * kTile];
   __shared__ double diag[kTile];
   __shared__ double s_scale;
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   cacc *= scale * scale;
   const bool inside = (i0 + ty < n && j0 + tx < n);
   if (inside) C[(int64_t)(i0 + ty) * n + (j0 + tx)] = cacc;
+  if (inside && C_keep) C_keep[(int64_t)(i0 + ty) * n + (j0 + tx)] = cacc;   // step 0: G_0 = M M^T is kept for the finish
   {
     // this tile's contribution to |G_s|_F^2
     double sq = inside ? cacc * cacc : 0.0;
@@ -200,13 +201,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
   Zt[idx] = Z[(int64_t)a * B + b];
 }
 
-// ---- finish: seed = dominant column of G (normalised); y = M^T seed; x = M y ------------------
-// F1: every workgroup derives the seed redundantly (n <= 1024: cheap, deterministic), workgroup 0
-//     stores it; each workgroup then produces 32 entries of y with 8 row groups per column.
-__global__ __launch_bounds__(256) void rank1_seed_y_kernel(const double* __restrict__ M, int n, int k,
-                                                          const double* __restrict__ buf0, const double* __restrict__ buf1,
-                                                          const Rank1Ctl* __restrict__ ctl, int last_buf,
-                                                          double* __restrict__ y) {
+// ---- finish: seed = dominant column of G (normalised); y = M^T seed; x = M y = G_0 seed ---------
+// F1: every workgroup derives the seed redundantly (n <= 1024: cheap, deterministic).  The first ny_blocks
+//     workgroups then produce 32 entries of y = M^T seed each (8 row groups per column); the others produce 4
+//     entries of x each.  x = M (M^T seed) = G_0 seed with G_0 = M M^T kept from step 0, so x does not wait for y:
+//     one launch instead of two (round 2).  A zero row of M is a zero row of G_0: its entry of x is exactly 0, as
+//     a zero column of M gives an exact 0 in y (tests/test_tpls.py:98-104 relies on both).
+__global__ __launch_bounds__(256) void rank1_seed_xy_kernel(const double* __restrict__ M, int n, int k,
+                                                           const double* __restrict__ buf0, const double* __restrict__ buf1,
+                                                           const double* __restrict__ G0,
+                                                           const Rank1Ctl* __restrict__ ctl, int last_buf, int ny_blocks,
+                                                           double* __restrict__ y, double* __restrict__ x) {
   extern __shared__ double seed[];        // n doubles
   __shared__ double red[16];
   __shared__ double rsum[8][33];
@@ -243,6 +248,18 @@ __global__ __launch_bounds__(256) void rank1_seed_y_kernel(const double* __restr
   const double nrm = sqrt(block_sum(ss, red));
   for (int i = threadIdx.x; i < n; i += 256) seed[i] = seed[i] / nrm;
   __syncthreads();
+  if ((int)blockIdx.x >= ny_blocks) {
+    // x[j] = sum_i G_0[j, i] seed[i]      one wavefront per row
+    const int j = ((int)blockIdx.x - ny_blocks) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j < n) {
+      double s = 0.0;
+      for (int i = lane; i < n; i += 64) s = fma(G0[(int64_t)j * n + i], seed[i], s);
+      s = wave_sum(s);
+      if (lane == 0) x[j] = s;
+    }
+    return;
+  }
   // y[c] = sum_j M[j, c] seed[j]
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
@@ -257,18 +274,6 @@ __global__ __launch_bounds__(256) void rank1_seed_y_kernel(const double* __restr
     for (int g = 0; g < 8; ++g) tot += rsum[g][cx];
     y[c] = tot;
   }
-}
-
-// F2: x[j] = sum_c M[j, c] y[c]      one wavefront per row
-__global__ __launch_bounds__(256) void rank1_x_kernel(const double* __restrict__ M, int n, int k,
-                                                     const double* __restrict__ y, double* __restrict__ x) {
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (j >= n) return;
-  double s = 0.0;
-  for (int c = lane; c < k; c += 64) s = fma(M[(int64_t)j * k + c], y[c], s);
-  s = wave_sum(s);
-  if (lane == 0) x[j] = s;
 }
 
 // F3: normalise x and y, apply the sign rule, write wA / wB / sigma / info   (1024 threads; x, y may
@@ -336,7 +341,7 @@ extern "C" {
 size_t cmtfpls_rank1_workspace_bytes(int A, int B) {
   if (A <= 0 || B <= 0) return 0;
   const size_t n = (size_t)(A < B ? A : B), k = (size_t)(A < B ? B : A);
-  return align_up(sizeof(Rank1Ctl), 256) + 2 * align_up(n * n * sizeof(double), 256) +
+  return align_up(sizeof(Rank1Ctl), 256) + 3 * align_up(n * n * sizeof(double), 256) +
          align_up((size_t)A * B * sizeof(double), 256) + align_up(n * sizeof(double), 256) + align_up(k * sizeof(double), 256);
 }
 
@@ -356,6 +361,8 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
   p += align_up((size_t)n * n * sizeof(double), 256);
   double* buf1 = reinterpret_cast<double*>(p);
   p += align_up((size_t)n * n * sizeof(double), 256);
+  double* g0keep = reinterpret_cast<double*>(p);
+  p += align_up((size_t)n * n * sizeof(double), 256);
   double* Zt = reinterpret_cast<double*>(p);
   p += align_up((size_t)A * B * sizeof(double), 256);
   double* xv = reinterpret_cast<double*>(p);
@@ -371,17 +378,16 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
   const int nt = (n + kTile - 1) / kTile;
   const dim3 grid(nt, nt), block(kTile, kTile);
   // step 0: G_0 = M0 M0^T -> buf0 ; step s: G_s = scale^2 G_{s-1} G_{s-1}^T -> buf[s & 1]
-  hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, M0, n, k, k, buf0, ctl, 0, 0);
+  hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, M0, n, k, k, buf0, ctl, 0, 0, g0keep);
   for (int s = 1; s <= n_squarings; ++s) {
     const double* in = (s & 1) ? buf0 : buf1;
     double* out = (s & 1) ? buf1 : buf0;
-    hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, in, n, n, n, out, ctl, s, s & 1);
+    hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, in, n, n, n, out, ctl, s, s & 1, (double*)nullptr);
   }
-  // (a single-workgroup fusion of the three finish kernels was measured: no faster than these three
-  // parallel launches, so the epilogue stays split)
-  hipLaunchKernelGGL(rank1_seed_y_kernel, dim3((k + 31) / 32), dim3(256), (size_t)n * sizeof(double), st,
-                     M0, n, k, buf0, buf1, ctl, n_squarings & 1, yv);
-  hipLaunchKernelGGL(rank1_x_kernel, dim3((n + 3) / 4), dim3(256), 0, st, M0, n, k, yv, xv);
+  // (a single-workgroup fusion of the finish kernels was measured in round 1: no faster than parallel launches)
+  const int ny_blocks = (k + 31) / 32;
+  hipLaunchKernelGGL(rank1_seed_xy_kernel, dim3(ny_blocks + (n + 3) / 4), dim3(256), (size_t)n * sizeof(double), st,
+                     M0, n, k, buf0, buf1, g0keep, ctl, n_squarings & 1, ny_blocks, yv, xv);
   hipLaunchKernelGGL(rank1_final_kernel, dim3(1), dim3(1024), 0, st, xv, yv, n, k, (A <= B) ? 1 : 0, ctl, wA, wB, sigma, info);
   return check_launch("rank1");
 }
