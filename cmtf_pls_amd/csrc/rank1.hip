@@ -3,8 +3,8 @@
 // (tpls.py:86-88, cmtf.py:100-102).  LAPACK is not available on the device and a plain power
 // iteration converges at (s2/s1)^2 per step, so the Gram matrix G of the smaller side is squared
 // repeatedly instead: after s squarings G^(2^s) is rank one to (s2/s1)^(2^(s+1)); each squaring is
-// one n x n x n f64 product (n <= 256 for the benchmark shapes) spread over (n/16)^2 workgroups
-// that stage their two 16-row panels in LDS with all loads in flight at once.  Scaling between
+// one n x n x n f64 product (n <= 256 for the benchmark shapes) spread over (n/16)^2 workgroups, each
+// 16 x 16 tile on the f64 matrix cores with its operands loaded straight into the MFMA layout.  Scaling between
 // squarings is by an exact power of two taken from the trace, so the iteration is
 // bit-reproducible; it stops early (later launches return at once) when tr(G^2) == tr(G)^2 to
 // 1e-13.  The dominant column of the final G then seeds one exact pass y = M^T seed, x = M y (= G_0 seed) with
