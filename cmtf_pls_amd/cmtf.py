@@ -40,8 +40,12 @@ class ctPLS(_EstimatorBase):
         self.Y_shape = tuple(Y2.shape)
         Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=self._copy_X) for X in Xs]
         Yd = to_device_copy(Y2, torch.float64, dev)
+        def notice(blocks):                                               # during preprocess, before the loop: cmtf.py:78-79
+            if any(b.has_miss for b in blocks):
+                print("At least one X has missing values")
+
         st = eng.fit(Xd, Yd, self.n_components, tol, max_iter, coupled=True, verbose=verbose, algorithm=self._algorithm,
-                     use_graphs=self._graphs, mixed=self._mixed)
+                     use_graphs=self._graphs, mixed=self._mixed, on_preprocessed=notice)
         del Xd
         self._state = st
         self.factor_T = st.T.cpu().numpy()
@@ -53,8 +57,6 @@ class ctPLS(_EstimatorBase):
         self.Xs_mean = [blk.mean.cpu().numpy().reshape(shape[1:]) for blk, shape in zip(st.blocks, self.Xs_shape)]
         self.Y_mean = st.y_mean.cpu().numpy()
         self.Xs_hasMiss = [blk.has_miss for blk in st.blocks]
-        if any(self.Xs_hasMiss):
-            print("At least one X has missing values")                    # cmtf.py:78-79
         # kept by reference for the lazy Xs_miss (cmtf.py:80-82); with copy_X=False the blocks were fitted in place
         self._Xs_in, self._Xs_miss = (Xs if self._copy_X else [None] * len(Xs)), None
         self.n_iter_ = list(st.n_iter)

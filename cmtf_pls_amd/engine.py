@@ -173,12 +173,14 @@ class NipalsEngine:
 
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
             coupled: bool, verbose: int = 0, algorithm: str = "direct", use_graphs: bool = False,
-            mixed: bool = False) -> FitState:
+            mixed: bool = False, on_preprocessed=None) -> FitState:
         """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy.
         algorithm: "direct" = the reference's loop (two X reads per iteration); "xcov" = the same
         iteration re-associated through S = X_(0)^T Y (one X read + one read/write per component)."""
         with self.device_ctx():
             run = self.begin(Xs, Y, n_components, coupled, algorithm)
+            if on_preprocessed is not None:                          # the estimators print their missing-value notice
+                on_preprocessed(run.blocks)                          # here, where the reference does (tpls.py:62-63)
             run.tol = tol                                            # also handed to parafac (tpls.py:86)
             run.use_graphs = bool(use_graphs) and getattr(self.be, "name", "") == "hip"
             run.mixed = bool(mixed)

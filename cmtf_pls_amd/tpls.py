@@ -141,14 +141,16 @@ class tPLS(_EstimatorBase):
         self.Y_shape = tuple(Y2.shape)
         Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=self._copy_X)
         Yd = to_device_copy(Y2, torch.float64, dev)
+        def notice(blocks):                                               # during preprocess, before the loop: tpls.py:62-63
+            if blocks[0].has_miss:
+                print("X has missing values")
+
         st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose, algorithm=self._algorithm,
-                     use_graphs=self._graphs, mixed=self._mixed)
+                     use_graphs=self._graphs, mixed=self._mixed, on_preprocessed=notice)
         del Xd
         blk = st.blocks[0]
         self._state = st
         self.X_hasMiss = blk.has_miss
-        if self.X_hasMiss:
-            print("X has missing values")                                 # tpls.py:62-63
         self._X_miss = None                       # X_miss (np.isnan(X), tpls.py:64) is built on first access
         self.X_factors = [st.T.cpu().numpy()] + [L.cpu().numpy() for L in blk.loadings]
         self.Y_factors = [st.U.cpu().numpy(), st.Q.cpu().numpy()]

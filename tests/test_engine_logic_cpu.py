@@ -288,3 +288,22 @@ def test_random_problems_match_oracle(seed):
     np.testing.assert_allclose(r2x, fit.r2x[0], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(tr, want_tr, rtol=1e-6, atol=1e-8)
+
+
+def test_stdout_side_effects_follow_the_reference_order(capsys):
+    """tpls.py:62-63 prints the missing-value notice during preprocess, tpls.py:104-105 the 0-based break index per
+    component under verbose; cmtf.py:78-79, 125-126 likewise."""
+    x, y, _ = O.import_synthetic((40, 6, 5), 2, 2, error=0.1, seed=8)
+    x[3, 2, 1] = np.nan
+    m = tPLS(2, backend=NumpyBackend())
+    m.fit(x, y, verbose=1)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out[0] == "X has missing values"
+    assert [ln.split(":")[0] for ln in out[1:]] == ["Comp 0", "Comp 1"]
+    assert out[1] == "Comp 0: converged after {} iterations".format(m.n_iter_[0] - 1)
+    c = ctPLS(2, backend=NumpyBackend())
+    c.fit([x, x[:, :, 0]], y)
+    assert capsys.readouterr().out.strip().splitlines()[0] == "At least one X has missing values"
+    q = tPLS(2, backend=NumpyBackend())
+    q.fit(np.nan_to_num(x), y)
+    assert capsys.readouterr().out == ""
