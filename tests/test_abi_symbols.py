@@ -45,3 +45,20 @@ def test_binding_table_matches_header(lib_path):
     assert lib.cmtfpls_sweep_partials() > 0
     assert lib.cmtfpls_mode0_contract_workspace_bytes(65536, 16384) > 0      # pure host arithmetic
     assert lib.cmtfpls_rank1_workspace_bytes(128, 128) > 0
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/cmtfpls.h must compile as C99 (and as C++) with no torch / HIP types."""
+    import shutil
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "cmtfpls.h"\nint main(void) { return cmtfpls_abi_version == 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not installed")
+        extra = ["-x", "c++"] if cc == "g++" else []
+        p = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-I", inc] + extra + [str(src)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+    text = open(os.path.join(inc, "cmtfpls.h")).read()
+    assert "torch" not in text.lower().replace("torch tensor's data_ptr", "") and "hipStream_t stream" not in text
