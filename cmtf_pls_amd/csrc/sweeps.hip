@@ -34,13 +34,16 @@ struct ContractPlan {
 
 constexpr int kDcU = 2;   // column groups per thread of deflate_contract_kernel (it also keeps wB entries and writes back)
 
-static ContractPlan plan_contract(int64_t I, int64_t P, int elem, int U = kContractU) {
+constexpr int kContractBlocksFull = 512;   // workgroups of the guard-free (FULL) contraction: 7.0 TB/s against 6.0 with 1024
+                                          // at 65536 x 128 x 128 (profiles/r02r_tune_full.txt); the guarded form keeps 1024
+
+static ContractPlan plan_contract(int64_t I, int64_t P, int elem, int U = kContractU, int blocks = kContractBlocks) {
   ContractPlan p;
   const int V = 16 / elem;
   p.vec = (P % V == 0) ? 1 : 0;
   const int64_t tile = p.vec ? (int64_t)kSweepThreads * V * U : kSweepThreads;
   p.col_tiles = (int)((P + tile - 1) / tile);
-  int64_t want = (kContractBlocks + p.col_tiles - 1) / p.col_tiles;   // ~1024 workgroups in all
+  int64_t want = (blocks + p.col_tiles - 1) / p.col_tiles;            // ~`blocks` workgroups in all
   if (want < 1) want = 1;
   int64_t rpb = (I + want - 1) / want;
   if (rpb < 16) rpb = 16;                                           // amortise the partial store
@@ -77,7 +80,9 @@ __device__ __forceinline__ void rows_times_q(const double* __restrict__ Y, int l
 
 // MODE 0: plain (NaN propagates, as np.einsum)  1: NaN -> 0  2: statistics (u == 1, NaN -> 0, count)
 // YQ: u is not read; u[i] = Y[i, :] . q is formed per workgroup in LDS, kYqChunk rows at a time
-template <typename T, int MODE, bool YQ, int U>
+// FULL: every column group of every thread exists (P is a multiple of the column tile): no guards, so the 4 x U loads
+// of a trip are issued back to back (with guards each load sits in its own exec-masked block).
+template <typename T, int MODE, bool YQ, int U, bool FULL>
 __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
     double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block,
@@ -93,11 +98,11 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
   bool ok[U];
 #pragma unroll
   for (int g = 0; g < U; ++g) {
-    ok[g] = cbase + (int64_t)g * kSweepThreads * V < P;
+    ok[g] = FULL || cbase + (int64_t)g * kSweepThreads * V < P;
 #pragma unroll
     for (int e = 0; e < V; ++e) { acc[g][e] = 0.0; cnt[g][e] = 0.0; }
   }
-  constexpr int RU = kUnroll;
+  constexpr int RU = FULL ? 2 : kUnroll;             // rows in flight per thread (x U loads each)
   // YQ: the workgroup's rows go through LDS in chunks of kYqChunk rows of u (16 KB), whatever rows_per_block is
   const int64_t rend = r1;
   for (int64_t rc0 = r0; rc0 < rend; rc0 += (YQ ? (int64_t)kYqChunk : rend - r0)) {
@@ -116,13 +121,13 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
       uu[s] = (MODE == 2) ? 1.0 : YQ ? us[r + s - r0] : u[r + s];
 #pragma unroll
       for (int g = 0; g < U; ++g)
-        if (ok[g]) x[s][g] = ld_stream(reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V));
+        if (FULL || ok[g]) x[s][g] = ld_stream(reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V));
     }
 #pragma unroll
     for (int s = 0; s < RU; ++s)
 #pragma unroll
       for (int g = 0; g < U; ++g)
-        if (ok[g]) {
+        if (FULL || ok[g]) {
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             const T xv = x[s][g].e[e];
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     const double ur = (MODE == 2) ? 1.0 : YQ ? us[r - r0] : u[r];
 #pragma unroll
     for (int g = 0; g < U; ++g)
-      if (ok[g]) {
+      if (FULL || ok[g]) {
         const VT x = ld_stream(reinterpret_cast<const VT*>(X + r * P + cbase + (int64_t)g * kSweepThreads * V));
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
   }   // chunks
 #pragma unroll
   for (int g = 0; g < U; ++g)
-    if (ok[g]) {
+    if (FULL || ok[g]) {
       const int64_t c = cbase + (int64_t)g * kSweepThreads * V;
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -545,14 +550,22 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   // column groups per thread: 4 (wider tiles, half as many partial rows per column: +2.8 % at 65536 rows) when a
   // workgroup still gets >= 128 rows, else 2 (shards of <= 16 K rows: 94 vs 101 us at 8192 x 128 x 128,
   // profiles/r02g_tune_small.txt); the statistics pass carries a second set of accumulators and stays at 2
-  const bool wideU = MODE != 2 && kContractU == 4 && plan_contract(I, P, (int)sizeof(T), 4).rows_per_block >= 128;
-  const ContractPlan p = plan_contract(I, P, (int)sizeof(T), wideU ? 4 : 2);
+  constexpr int Vp = 16 / (int)sizeof(T);
+  const bool vecp = (P % Vp) == 0;
+  const bool full4 = vecp && (P % ((int64_t)kSweepThreads * Vp * 4)) == 0, full2 = vecp && (P % ((int64_t)kSweepThreads * Vp * 2)) == 0;
+  const ContractPlan p4 = plan_contract(I, P, (int)sizeof(T), 4, full4 ? kContractBlocksFull : kContractBlocks);
+  const bool wideU = MODE != 2 && kContractU == 4 && p4.rows_per_block >= 128;
+  const ContractPlan p = wideU ? p4 : plan_contract(I, P, (int)sizeof(T), 2, full2 ? kContractBlocksFull : kContractBlocks);
+  const bool fullt = wideU ? full4 : full2;
+#define CV_LAUNCH1(YQF, UU, FF, LDS, UPTR, YP, LDY, MM, QP)                                                                          \
+  hipLaunchKernelGGL((contract_vec_kernel<T, MODE, YQF, UU, FF>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR, part, cntpart,    \
+                     p.rows_per_block, YP, LDY, MM, QP)
 #define CV_LAUNCH(YQF, LDS, UPTR, YP, LDY, MM, QP)                                                                                   \
   do {                                                                                                                               \
-    if (wideU) hipLaunchKernelGGL((contract_vec_kernel<T, MODE, YQF, (MODE == 2) ? 2 : 4>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR, \
-                                  part, cntpart, p.rows_per_block, YP, LDY, MM, QP);                                                  \
-    else hipLaunchKernelGGL((contract_vec_kernel<T, MODE, YQF, 2>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR, part, cntpart, \
-                            p.rows_per_block, YP, LDY, MM, QP);                                                                       \
+    if (wideU && fullt) CV_LAUNCH1(YQF, ((MODE == 2) ? 2 : 4), true, LDS, UPTR, YP, LDY, MM, QP);                                     \
+    else if (wideU) CV_LAUNCH1(YQF, ((MODE == 2) ? 2 : 4), false, LDS, UPTR, YP, LDY, MM, QP);                                        \
+    else if (fullt) CV_LAUNCH1(YQF, 2, true, LDS, UPTR, YP, LDY, MM, QP);                                                            \
+    else CV_LAUNCH1(YQF, 2, false, LDS, UPTR, YP, LDY, MM, QP);                                                                      \
   } while (0)
   // Wide blocks (>= kYqUnfuseTiles column tiles): every column tile of a row block would repeat the same
   // u = Y q prologue, so u is formed once by the rowdot kernel into the tail of the workspace instead
@@ -595,6 +608,7 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   launch_reduce_rows(part, p.row_blocks, P, out, st);
   if (MODE == 2) launch_reduce_rows(cntpart, p.row_blocks, P, cnt_out, st);
 #undef CV_LAUNCH
+#undef CV_LAUNCH1
   return check_launch("mode0_contract");
 }
 
@@ -1428,7 +1442,11 @@ size_t cmtfpls_mode0_contract_workspace_bytes(int64_t I, int64_t P) {
   // sized for every plan a call may choose (f32 / f64 vectors, the statistics pass's narrower column tiles)
   int rb = 1;
   for (int elem = 4; elem <= 8; elem += 4)
-    for (int U = 2; U <= kContractU; U += 2) { const int r = plan_contract(I, P, elem, U).row_blocks; if (r > rb) rb = r; }
+    for (int U = 2; U <= kContractU; U += 2)
+      for (int blocks = kContractBlocksFull; blocks <= kContractBlocks; blocks += kContractBlocks - kContractBlocksFull) {
+        const int r = plan_contract(I, P, elem, U, blocks).row_blocks;
+        if (r > rb) rb = r;
+      }
   return (size_t)rb * (size_t)P * sizeof(double) + (size_t)I * sizeof(double);   // + u = Y q of the wide-block form
 }
 size_t cmtfpls_colstats_workspace_bytes(int64_t I, int64_t P) { return 2 * cmtfpls_mode0_contract_workspace_bytes(I, P); }

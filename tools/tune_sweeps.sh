@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "u2cb1024:-DCMTFPLS_CONTRACT_U=2" "u4cb512:-DCMTFPLS_CONTRACT_BLOCKS=512" "u2cb512:-DCMTFPLS_CONTRACT_U=2 -DCMTFPLS_CONTRACT_BLOCKS=512" "u4cb256:-DCMTFPLS_CONTRACT_BLOCKS=256" "u2cb2048:-DCMTFPLS_CONTRACT_U=2 -DCMTFPLS_CONTRACT_BLOCKS=2048")
+VARIANTS=("base:" "cb512:-DCMTFPLS_CONTRACT_BLOCKS=512" "cb640:-DCMTFPLS_CONTRACT_BLOCKS=640" "cb768:-DCMTFPLS_CONTRACT_BLOCKS=768" "cb512r2:-DCMTFPLS_CONTRACT_BLOCKS=512 -DCMTFPLS_UNROLL=2" "u2cb512:-DCMTFPLS_CONTRACT_U=2 -DCMTFPLS_CONTRACT_BLOCKS=512" "u2cb1024:-DCMTFPLS_CONTRACT_U=2")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
