@@ -34,7 +34,13 @@ struct ContractPlan {
 
 constexpr int kDcU = 2;   // column groups per thread of deflate_contract_kernel (it also keeps wB entries and writes back)
 
-constexpr int kContractBlocksFull = 512;   // workgroups of the guard-free (FULL) contraction: 7.0 TB/s against 6.0 with 1024
+#ifndef CMTFPLS_CONTRACT_BLOCKS_FULL
+#define CMTFPLS_CONTRACT_BLOCKS_FULL 512
+#endif
+#ifndef CMTFPLS_UNROLL_FULL
+#define CMTFPLS_UNROLL_FULL 2
+#endif
+constexpr int kContractBlocksFull = CMTFPLS_CONTRACT_BLOCKS_FULL;   // workgroups of the guard-free (FULL) contraction: 7.0 TB/s against 6.0 with 1024
                                           // at 65536 x 128 x 128 (profiles/r02r_tune_full.txt); the guarded form keeps 1024
 
 static ContractPlan plan_contract(int64_t I, int64_t P, int elem, int U = kContractU, int blocks = kContractBlocks) {
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
 #pragma unroll
     for (int e = 0; e < V; ++e) { acc[g][e] = 0.0; cnt[g][e] = 0.0; }
   }
-  constexpr int RU = FULL ? 2 : kUnroll;             // rows in flight per thread (x U loads each)
+  constexpr int RU = FULL ? CMTFPLS_UNROLL_FULL : kUnroll;   // rows in flight per thread (x U loads each)
   // YQ: the workgroup's rows go through LDS in chunks of kYqChunk rows of u (16 KB), whatever rows_per_block is
   const int64_t rend = r1;
   for (int64_t rc0 = r0; rc0 < rend; rc0 += (YQ ? (int64_t)kYqChunk : rend - r0)) {
@@ -1443,8 +1449,8 @@ size_t cmtfpls_mode0_contract_workspace_bytes(int64_t I, int64_t P) {
   int rb = 1;
   for (int elem = 4; elem <= 8; elem += 4)
     for (int U = 2; U <= kContractU; U += 2)
-      for (int blocks = kContractBlocksFull; blocks <= kContractBlocks; blocks += kContractBlocks - kContractBlocksFull) {
-        const int r = plan_contract(I, P, elem, U, blocks).row_blocks;
+      for (int which = 0; which < 2; ++which) {
+        const int r = plan_contract(I, P, elem, U, which ? kContractBlocks : kContractBlocksFull).row_blocks;
         if (r > rb) rb = r;
       }
   return (size_t)rb * (size_t)P * sizeof(double) + (size_t)I * sizeof(double);   // + u = Y q of the wide-block form

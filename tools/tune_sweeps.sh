@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "cb512:-DCMTFPLS_CONTRACT_BLOCKS=512" "cb640:-DCMTFPLS_CONTRACT_BLOCKS=640" "cb768:-DCMTFPLS_CONTRACT_BLOCKS=768" "cb512r2:-DCMTFPLS_CONTRACT_BLOCKS=512 -DCMTFPLS_UNROLL=2" "u2cb512:-DCMTFPLS_CONTRACT_U=2 -DCMTFPLS_CONTRACT_BLOCKS=512" "u2cb1024:-DCMTFPLS_CONTRACT_U=2")
+VARIANTS=("base:" "f1024:-DCMTFPLS_CONTRACT_BLOCKS_FULL=1024" "f768:-DCMTFPLS_CONTRACT_BLOCKS_FULL=768" "f2048:-DCMTFPLS_CONTRACT_BLOCKS_FULL=2048" "f512r4:-DCMTFPLS_UNROLL_FULL=4" "f1024r4:-DCMTFPLS_CONTRACT_BLOCKS_FULL=1024 -DCMTFPLS_UNROLL_FULL=4" "f256:-DCMTFPLS_CONTRACT_BLOCKS_FULL=256")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
