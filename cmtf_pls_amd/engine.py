@@ -870,6 +870,8 @@ class FitRun:
     def result(self) -> FitState:
         """The only device -> host traffic of the component epilogues: the R x R coefficients and the
         R x (blocks + 1) deflated norms, all-reduced once, in one copy."""
+        if getattr(self, "_state", None) is not None:             # the norms are all-reduced exactly once
+            return self._state
         nb = len(self.blocks)
         self.eng.comm.allreduce(self.ssq_log)
         host = torch.cat([self.coef_dev.reshape(-1), self.ssq_log.reshape(-1)]).cpu().numpy()
@@ -880,6 +882,7 @@ class FitRun:
             for b, blk in enumerate(self.blocks):
                 blk.r2x[a] = 1.0 - ssq[a, b] / blk.ssq0                          # tpls.py:115-117
             self.r2y[a] = 1.0 - ssq[a, nb] / self.ssqy0                          # tpls.py:118-120
-        return FitState(coupled=self.coupled, n_components=self.R, blocks=self.blocks, T=self.T, U=self.U, Q=self.Q,
-                        coef=self.coef, r2y=self.r2y, y_mean=self.y_mean, n_iter=self.n_iter,
-                        n_samples_total=self.n_total)
+        self._state = FitState(coupled=self.coupled, n_components=self.R, blocks=self.blocks, T=self.T, U=self.U, Q=self.Q,
+                               coef=self.coef, r2y=self.r2y, y_mean=self.y_mean, n_iter=self.n_iter,
+                               n_samples_total=self.n_total)
+        return self._state
