@@ -108,3 +108,33 @@ def test_random_shape(be, I, A, B, dt, masked):
             uu, vv = -uu, -vv
         np.testing.assert_allclose(host(wA), uu, rtol=0, atol=1e-9)
         np.testing.assert_allclose(host(wB), vv, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("A,B", [(1, 16), (4, 12)])
+def test_millions_of_short_rows(be, A, B):
+    """2.5 million rows of 16-48 elements: 64-bit row indexing in the short-row kernels (a wavefront owns several
+    whole rows), the narrow contraction, centring and the fused deflation + contraction."""
+    I = 2_500_003
+    P = A * B
+    rng = np.random.default_rng(7)
+    x = rng.normal(size=(I, P)).astype(np.float32)
+    wa, wb = rng.normal(size=A), rng.normal(size=B)
+    w = np.kron(wa, wb)
+    u = rng.normal(size=I)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    X = dev(x)
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(be.mode0_contract(X, dev(u), False).cpu().numpy(), x64.T @ u, rtol=1e-9, atol=1e-7)
+    t = be.score(X, A, B, dev(wa), dev(wb), None, be.empty(I)).cpu().numpy()
+    np.testing.assert_allclose(t, x64 @ w, rtol=1e-10, atol=1e-9)
+    tt = be.empty(I)
+    ssq = be.score_deflate(X, A, B, dev(wa), dev(wb), None, tt)
+    assert ssq is not None
+    want = (x64 - np.outer(t, w)).astype(np.float32)
+    got = X.cpu().numpy()
+    np.testing.assert_allclose(got[[0, 1, I // 2, I - 2, I - 1]], want[[0, 1, I // 2, I - 2, I - 1]], rtol=3e-7, atol=1e-7)
+    np.testing.assert_allclose(got, want, rtol=3e-7, atol=1e-6)
+    np.testing.assert_allclose(ssq.cpu().numpy()[0], float((want.astype(np.float64) ** 2).sum()), rtol=1e-9)
+    mean = torch.from_numpy(want.astype(np.float64).mean(0)).to("cuda:0")
+    rowcnt, _ = be.center(X, mean, True)
+    assert float(rowcnt.min()) == P and float(rowcnt.max()) == P
