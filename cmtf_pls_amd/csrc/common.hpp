@@ -120,6 +120,31 @@ struct KronWalk {
 };
 
 
+// XCD-aware (column tile, row block) of a workgroup of a (col_tiles x row_blocks) grid.  Workgroups are dealt to the 8
+// XCDs round-robin in dispatch order (linear id = blockIdx.x + gridDim.x * blockIdx.y), and every XCD has its own L2.
+// The column tiles of ONE row block share per-row operands (the Y rows behind u = Y q, t, u): this map puts them on
+// the SAME XCD (consecutive dispatch slots of that XCD), so those rows come from HBM once per row block instead of
+// once per column tile.  Row blocks are taken in groups of 8 (one per XCD); a ragged tail keeps the plain order.
+// A bijection for every grid shape.
+struct TileId { int ct, rb; };
+__device__ __forceinline__ TileId xcd_tile() {
+  const unsigned CT = gridDim.x, RB = gridDim.y;
+  const unsigned lin = blockIdx.x + CT * blockIdx.y;
+  const unsigned G = CT * 8u, groups = RB / 8u;
+  const unsigned grp = lin / G;
+  TileId id;
+  if (grp < groups) {
+    const unsigned within = lin - grp * G;
+    id.ct = (int)(within >> 3);
+    id.rb = (int)(grp * 8u + (within & 7u));
+  } else {
+    const unsigned rest = lin - groups * G;
+    id.ct = (int)(rest % CT);
+    id.rb = (int)(groups * 8u + rest / CT);
+  }
+  return id;
+}
+
 // launch plan shared by the f64 and the mixed-precision cross-covariance kernels (xcov.hip, mixed.hip)
 struct XcovPlan {
   int col_tiles, row_blocks, rows_per_block;

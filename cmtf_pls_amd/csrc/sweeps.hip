@@ -96,8 +96,9 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
   extern __shared__ double us[];
   constexpr int V = VecOf<T>::N;
   using VT = typename VecOf<T>::type;
-  const int64_t cbase = (int64_t)blockIdx.x * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const TileId tile = xcd_tile();                       // the column tiles of a row block share one XCD's L2
+  const int64_t cbase = (int64_t)tile.ct * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
+  const int64_t r0 = (int64_t)tile.rb * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
   double acc[U][V];
   double cnt[U][V];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
   const int64_t r0 = rc0;                                                   // chunk = [r0, r1) below
   const int64_t r1 = (YQ && rc0 + kYqChunk < rend) ? rc0 + kYqChunk : rend;
   if (YQ) {
-    if (rc0 != (int64_t)blockIdx.y * rows_per_block) __syncthreads();       // the previous chunk's readers are done
+    if (rc0 != (int64_t)tile.rb * rows_per_block) __syncthreads();          // the previous chunk's readers are done
     rows_times_q(Y, ldy, M, q, r0, r1, us);
   }
   int64_t r = r0;
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
       const int64_t c = cbase + (int64_t)g * kSweepThreads * V;
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        part[(int64_t)blockIdx.y * P + c + e] = acc[g][e];
-        if (MODE == 2) cntpart[(int64_t)blockIdx.y * P + c + e] = cnt[g][e];
+        part[(int64_t)tile.rb * P + c + e] = acc[g][e];
+        if (MODE == 2) cntpart[(int64_t)tile.rb * P + c + e] = cnt[g][e];
       }
     }
 }
