@@ -413,7 +413,8 @@ def main():
         S = torch.empty(M, J * K, dtype=torch.float64, device=device)
         Mo = torch.empty(rows, R, dtype=torch.float64, device=device)
         WA, WB = st.blocks[0].loadings[0].contiguous(), st.blocks[0].loadings[1].contiguous()
-        mfma = {"peak_TF": F64_MFMA_PEAK_TF, "note": "f64 matrix cores (v_mfma_f64_16x16x4_f64); utilisation = flops / (avg launch time x peak)"}
+        mfma = {"peak_TF": F64_MFMA_PEAK_TF, "note": "f64 matrix cores (v_mfma_f64_16x16x4_f64); utilisation = flops / (avg launch time x nominal peak at "
+                                                      "2.4 GHz); SQ-counter view at the clock the chip holds under this load: profiles/r02y_mfma_utilisation.json"}
         for name, fn, flops in (("xcov", lambda: be.xcov(X2, Y, False, out=S), 2.0 * rows * J * K * M),
                                 ("mttkrp", lambda: be.mttkrp(X2, J, K, WA, WB, Mo), 2.0 * rows * J * K * 16 * ((R + 15) // 16))):
             ms = timer.time_calls(fn, n=5, warm=1)

@@ -4,8 +4,9 @@
 One rocprofv3 pass (--pmc with --kernel-trace only, as the MI355X guide prescribes) over
 `tools/kernel_bench.py --only mfma`: SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipe is busy, summed over the
 SIMDs), SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE.  utilisation = MFMA busy cycles / (1024 SIMDs x effective clock x kernel
-time); effective clock = GRBM_GUI_ACTIVE / kernel time (the chip throttles under f64 MFMA load).
-Run on the GPU box:  python3 tools/mfma_utilisation.py [out.json]   (this process never touches the GPU)."""
+time); effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time (MI355X_MICROARCH.md, DVFS: the chip throttles under
+f64 MFMA load).  Run on the GPU box:  python3 tools/mfma_utilisation.py [out.json]   (this process never touches the
+GPU);  python3 tools/mfma_utilisation.py --parse [out.json] re-reads CSVs collected earlier."""
 import csv
 import glob
 import json
@@ -18,13 +19,15 @@ COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "mfma_utilisation.json")
+    args = [a for a in sys.argv[1:] if a != "--parse"]
+    out = args[0] if args else os.path.join(ROOT, "profiles", "mfma_utilisation.json")
     d = os.path.join(ROOT, "gpurun_out", "mfma_pmc")
     os.makedirs(d, exist_ok=True)
-    cmd = ["rocprofv3", "--pmc"] + COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "m", "--",
-                                               "python3", os.path.join(ROOT, "tools", "kernel_bench.py"), "--only", "mfma"]
-    with open(os.path.join(d, "run.log"), "w") as log:
-        subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=log, stderr=subprocess.STDOUT)
+    if "--parse" not in sys.argv:
+        cmd = ["rocprofv3", "--pmc"] + COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "m", "--",
+                                                   "python3", os.path.join(ROOT, "tools", "kernel_bench.py"), "--only", "mfma"]
+        with open(os.path.join(d, "run.log"), "w") as log:
+            subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=log, stderr=subprocess.STDOUT)
     cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     dur = {}
@@ -45,9 +48,10 @@ def main():
         t_ns = sum(r[0] for r in rows) / len(rows)
         busy = sum(r[1]["SQ_VALU_MFMA_BUSY_CYCLES"] for r in rows) / len(rows)
         gui = sum(r[1]["GRBM_GUI_ACTIVE"] for r in rows) / len(rows)
-        clock_ghz = gui / t_ns                      # cycles per ns (GRBM counts at the shader clock, one instance)
+        clock_ghz = gui / 8.0 / t_ns                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; cycles per ns
         res[kern] = {"dispatches": len(rows), "duration_us": t_ns / 1e3, "mfma_busy_cycles": busy, "grbm_gui_active": gui,
-                     "effective_clock_GHz_if_single_instance": clock_ghz,
+                     "effective_clock_GHz": clock_ghz,
+                     "mfma_utilisation_at_effective_clock": busy / (1024 * clock_ghz * t_ns),
                      "mfma_utilisation_at_2.4GHz": busy / (1024 * 2.4 * t_ns)}
     json.dump({"method": __doc__.split("\n\n")[1].replace("\n", " "), "workload": "65536x128x128 f32, M=16, R=10 (tools/kernel_bench.py --only mfma)",
                "kernels": res}, open(out, "w"), indent=1)
