@@ -295,3 +295,41 @@ def test_literal_r2x_on_device_equals_the_deflation_identity(shape, nan, dtype):
     assert abs(lit - m.R2X[-1]) < tol
     want = O.calc_r2x(x - np.nanmean(x, axis=0), O.cp_factors_to_tensor(m.X_factors))
     assert abs(lit - want) < tol
+
+
+# ---- randomised end-to-end problems on the HIP path (the CPU suite runs the same cases through the NumPy backend) ----
+@pytest.mark.parametrize("seed", range(100, 132))
+def test_random_problems_match_oracle_on_gpu(seed):
+    """Random orders (2-5), NaNs, 1-D or 2-D Y, tPLS or ctPLS (with an extra matrix block), both algorithms, float64
+    storage: HIP engine == oracle (scores, q, coef_, R2, iteration counts, transform of new rows, reconstruction)."""
+    from test_engine_logic_cpu import _random_case
+    from cmtf_pls_amd import ctPLS, tPLS
+    X, Y, R, algorithm, coupled, rng = _random_case(seed)
+    if coupled:
+        Xm = rng.normal(size=(X.shape[0], int(rng.integers(2, 7))))
+        m = ctPLS(R, algorithm=algorithm)
+        m.fit([X, Xm], Y)
+        fit = O.fit_ctpls([X, Xm], Y, R)
+        T, r2x = m.factor_T, m.R2Xs[0]
+        new = [X[::2].copy(), Xm[::2].copy()]
+        tr, want_tr = m.transform(new), O.transform(fit, new)
+        rec = m.Xs_reconstructed()[0]
+    else:
+        m = tPLS(R, algorithm=algorithm)
+        m.fit(X, Y)
+        fit = O.fit_tpls(X, Y, R)
+        T, r2x = m.X_factors[0], m.R2X
+        tr, want_tr = m.transform(X[::2]), O.transform(fit, X[::2])
+        rec = m.X_reconstructed()
+    if np.isnan(fit.T).any():            # an all-NaN row makes the reference itself produce NaN scores
+        assert np.isnan(T).any()
+        return
+    assert list(m.n_iter_) == list(fit.n_iter)
+    s = np.abs(fit.T).max()
+    np.testing.assert_allclose(T, fit.T, rtol=1e-6, atol=1e-8 * s)
+    np.testing.assert_allclose(m.Y_factors[1], fit.Q, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(m.coef_, fit.coef, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(r2x, fit.r2x[0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(tr, want_tr, rtol=1e-6, atol=1e-8 * s)
+    np.testing.assert_allclose(rec, O.reconstruct(fit, 0), rtol=1e-6, atol=1e-7 * max(1.0, np.nanmax(np.abs(X))))
