@@ -41,7 +41,11 @@ def _worker(rank, world, port, case, ret):
         x, y, cp = O.import_synthetic((60, 8, 6), 3, 3, error=0.1, seed=21)
         if case == "nan":
             x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
-        rows = slice(rank * 30, (rank + 1) * 30)
+        if world == 2:
+            rows = slice(rank * 30, (rank + 1) * 30)
+        else:                                                # uneven shards: 13 / 20 / 27 rows on 3 ranks
+            cuts = [0, 13, 33, 60]
+            rows = slice(cuts[rank], cuts[rank + 1])
         if case == "coupled":
             xm = cp.factors[0] @ np.random.default_rng(4).normal(size=(9, 3)).T
             m = ctPLS(3, backend=NumpyBackend(), comm=Comm())
@@ -82,6 +86,17 @@ def test_world2_matches_oracle(case):
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+@pytest.mark.parametrize("case", ["plain", "xcov"])
+def test_world3_uneven_shards_match_oracle(case):
+    """Three ranks with 13 / 20 / 27 rows: nothing in the engine assumes equal shards (the global sample count and
+    every column statistic are all-reduced)."""
+    world = 3
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok", 2: "ok"}, dict(ret)
 
 
 def _retry_worker(rank, world, port, ret):
