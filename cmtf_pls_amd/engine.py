@@ -141,9 +141,8 @@ class NipalsEngine:
         (tensorly parafac restated) for a tensor; fills the factored loading (wA, wB)."""
         order = len(blk.shape)
         if order == 2:
-            wB.copy_(Z)
+            wB.copy_(Z)                                   # wA of a matrix block is the constant [1]: set once in FitRun
             self.be.normalize(wB)
-            wA.fill_(1.0)
         elif order == 3:
             self.be.rank1(Z, blk.A, blk.B, wA, wB, info=info, n_squarings=n_squarings)
         else:
@@ -361,6 +360,9 @@ class FitRun:
             blk.loadings = [be.zeros(d, R) for d in blk.shape[1:]]
             blk.r2x = np.zeros(R)
         self.wA = [be.empty(blk.A) for blk in self.blocks]
+        for b, blk in enumerate(self.blocks):
+            if len(blk.shape) == 2:
+                self.wA[b].fill_(1.0)                     # a matrix block has A = 1 and w = wB: never written again
         self.wB = [be.empty(blk.B) for blk in self.blocks]
         self.Zs = [be.empty(blk.A * blk.B) for blk in self.blocks]
         self.fac = [be.zeros(len(blk.shape) - 1, max(blk.shape[1:])) if len(blk.shape) > 3 else None for blk in self.blocks]
