@@ -68,6 +68,7 @@ SIGNATURES = {
     "cmtfpls_unit_upper_solve_rows_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P]),
     "cmtfpls_kr_gram_f64": (c_int, [_P, c_int, c_int, _P, c_int, c_double, _P]),
     "cmtfpls_khatri_rao_f64": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
+    "cmtfpls_predict_rows_f64": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P, _P, c_int, _P]),
     "cmtfpls_recon_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
     "cmtfpls_recon_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
     "cmtfpls_recon_r2_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -306,6 +306,18 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_khatri_rao_f64(_ptr(Am), na, _ptr(Bm), nb, R, _ptr(out), self._stream()), "khatri_rao")
         return out
 
+    def predict_rows(self, S: torch.Tensor, Bm: torch.Tensor, mean: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """out (I, M) = S (I, R) @ Bm (R, M) + mean: the last line of predict (tpls.py:143) on the device-resident scores."""
+        I, R = S.shape
+        M = Bm.shape[1]
+        assert S.stride(1) == 1 and Bm.is_contiguous() and Bm.shape[0] == R
+        out = self.empty(I, M)
+        rc = self.lib.cmtfpls_predict_rows_f64(_ptr(S), I, S.stride(0), R, _ptr(Bm), M, _ptr(mean), _ptr(out), M, self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "predict_rows")
+        return out
+
     def recon(self, T: torch.Tensor, WA: torch.Tensor, WB: torch.Tensor, mean: Optional[torch.Tensor], out: torch.Tensor) -> Optional[torch.Tensor]:
         """out (I, A*B) = T (WA (.) WB)^T + mean in out's dtype (factors_to_tensor util.py:18-20 + X_mean);
         None when the shape is outside the vector form (caller falls back to the host einsum)."""

@@ -67,7 +67,7 @@ class ctPLS(_EstimatorBase):
             self._Xs_miss = [np.isnan(X) if isinstance(X, np.ndarray) else None for X in self._Xs_in]
         return self._Xs_miss
 
-    def _project(self, Xs) -> np.ndarray:
+    def _project_dev(self, Xs) -> torch.Tensor:
         assert len(Xs) == self.Xs_len                                     # cmtf.py:144,181
         for ti, X in enumerate(Xs):
             if self.Xs_shape[ti][1:] != tuple(X.shape[1:]):
@@ -76,10 +76,13 @@ class ctPLS(_EstimatorBase):
                 )
         eng = self._get_engine()
         Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device) for X in Xs]
-        return eng.project(self._state, Xd, mixed=self._mixed).cpu().numpy()
+        return eng.project(self._state, Xd, mixed=self._mixed)
+
+    def _project(self, Xs) -> np.ndarray:
+        return self._project_dev(Xs).cpu().numpy()
 
     def predict(self, Xs):
-        return self._project(Xs) @ self.coef_ @ self.Y_factors[1].T + self.Y_mean      # cmtf.py:177
+        return self._predict_from_scores(self._project_dev(Xs))                         # cmtf.py:177
 
     def transform(self, Xs, Y=None):
         X_scores = self._project(Xs)

@@ -111,6 +111,23 @@ __global__ __launch_bounds__(256) void khatri_rao_kernel(const double* __restric
   out[idx] = Am[(jk / nb) * R + r] * Bm[(jk % nb) * R + r];
 }
 
+// out[i, m] = mean[m] + sum_a S[i, a] Bm[a, m]: the last line of predict, `X_projection @ coef_ @ Q^T + Y_mean`
+// (tpls.py:143, cmtf.py:177), with Bm = coef_ Q^T (R x M) formed by the caller; one thread per output element.
+__global__ __launch_bounds__(256) void predict_rows_kernel(const double* __restrict__ S, int lds_, int R, const double* __restrict__ Bm,
+                                                          const double* __restrict__ mean, double* __restrict__ out, int ldo, int64_t I, int M) {
+  extern __shared__ double sb[];                    // Bm (R x M) then mean (M)
+  for (int idx = threadIdx.x; idx < R * M; idx += 256) sb[idx] = Bm[idx];
+  for (int idx = threadIdx.x; idx < M; idx += 256) sb[R * M + idx] = mean ? mean[idx] : 0.0;
+  __syncthreads();
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= I * M) return;
+  const int64_t i = o / M;
+  const int m = (int)(o % M);
+  double acc = 0.0;
+  for (int a = 0; a < R; ++a) acc = fma(S[i * lds_ + a], sb[a * M + m], acc);
+  out[i * ldo + m] = acc + sb[R * M + m];
+}
+
 }  // namespace cmtfpls
 
 using namespace cmtfpls;
@@ -135,6 +152,17 @@ int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, dou
   if (!L || !G || n <= 0 || R <= 0) { set_error("kr_gram: bad argument"); return CMTFPLS_EINVAL; }
   hipLaunchKernelGGL(kr_gram_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, L, n, R, G, first, scale);
   return check_launch("kr_gram");
+}
+
+int cmtfpls_predict_rows_f64(const double* S, int64_t I, int lds_, int R, const double* Bm, int M, const double* mean, double* out, int ldo,
+                             void* stream) {
+  if (!S || !Bm || !out || I <= 0 || R <= 0 || M <= 0 || lds_ < R || ldo < M) { set_error("predict_rows: bad argument"); return CMTFPLS_EINVAL; }
+  const size_t lds_bytes = ((size_t)R * M + M) * sizeof(double);
+  if (lds_bytes > 64 * 1024) { set_error("predict_rows: coef_ Q^T does not fit the LDS"); return CMTFPLS_EUNSUPPORTED; }
+  const int64_t tot = I * M;
+  hipLaunchKernelGGL(predict_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), lds_bytes, (hipStream_t)stream, S, lds_, R, Bm, mean,
+                     out, ldo, I, M);
+  return check_launch("predict_rows");
 }
 
 int cmtfpls_khatri_rao_f64(const double* Am, int na, const double* Bm, int nb, int R, double* out, void* stream) {

@@ -37,14 +37,25 @@ def _as_torch_dtype(dtype, like) -> torch.dtype:
 def to_device_copy(X, dtype: torch.dtype, device, copy: bool = True) -> torch.Tensor:
     """A fresh contiguous device tensor of X (inputs are never modified, tpls.py:74,128,151).
     copy=False (opt-in ``copy_X=False``): a device tensor that already has the right type is used in
-    place and is centred / deflated by the fit."""
+    place and is centred / deflated by the fit.
+
+    A large HOST array of another type than the storage type (the common case: float64 NumPy input, float32
+    storage) is shipped in row blocks in ITS OWN type and cast on the device: casting 8.6 GB on the host first costs
+    ~0.75 s at 65536 x 128 x 128, the extra PCIe bytes ~0.08 s (profiles/r02aa_pcie_inclusive.txt)."""
     if isinstance(X, torch.Tensor):
         if not copy and X.is_contiguous() and X.dtype == dtype and X.device == torch.device(device):
             return X
         out = X.to(device=device, dtype=dtype, copy=True)
-    else:
-        out = torch.from_numpy(np.ascontiguousarray(X)).to(device=device, dtype=dtype, copy=True)
-    return out.contiguous()
+        return out.contiguous()
+    Xn = np.ascontiguousarray(X)
+    src = torch.from_numpy(Xn)
+    if src.dtype == dtype or Xn.ndim == 0 or Xn.nbytes < (64 << 20):
+        return src.to(device=device, dtype=dtype, copy=True).contiguous()
+    out = torch.empty(Xn.shape, dtype=dtype, device=device)
+    rows = max(1, (256 << 20) // max(Xn[0].nbytes, 1))           # ~256 MB of the source type per block
+    for r in range(0, Xn.shape[0], rows):
+        out[r:r + rows].copy_(src[r:r + rows].to(device))        # H2D in the source type, cast by the device copy
+    return out
 
 
 class _EstimatorBase(Mapping):
@@ -95,6 +106,19 @@ class _EstimatorBase(Mapping):
             out = factors_to_tensor(f) + mean
             return torch.from_numpy(out) if device else out
         return rec if device else rec.cpu().numpy().astype(np.float64)
+
+    def _predict_from_scores(self, scores_dev: torch.Tensor) -> np.ndarray:
+        """`X_projection @ coef_ @ Q^T + Y_mean` (tpls.py:143, cmtf.py:177); on the device when the backend has the
+        kernel (a 65536 x 10 by 10 x 16 host matmul costs 20 ms of BLAS thread start-up on a 256-core host)."""
+        Bm = self.coef_ @ self.Y_factors[1].T                                        # R x M, tiny
+        be = self._get_engine().be
+        if hasattr(be, "predict_rows") and scores_dev.is_cuda:
+            with self._get_engine().device_ctx():
+                out = be.predict_rows(scores_dev, torch.from_numpy(np.ascontiguousarray(Bm)).to(scores_dev.device),
+                                      torch.from_numpy(np.ascontiguousarray(self.Y_mean, dtype=np.float64)).to(scores_dev.device))
+            if out is not None:
+                return out.cpu().numpy()
+        return scores_dev.cpu().numpy() @ Bm + self.Y_mean
 
     # shared Y-side epilogue of transform (tpls.py:167-184, cmtf.py:212-229) -- host NumPy, I' x M only
     def _y_scores(self, X_scores: np.ndarray, Y) -> np.ndarray:
@@ -169,15 +193,18 @@ class tPLS(_EstimatorBase):
             self._X_miss = np.isnan(self.original_X)
         return self._X_miss
 
-    def _project(self, X) -> np.ndarray:
+    def _project_dev(self, X) -> torch.Tensor:
         if self.X_shape[1:] != tuple(X.shape[1:]):
             raise ValueError(f"Training X has shape {self.X_shape}, while the new X has shape {tuple(X.shape)}")
         eng = self._get_engine()
         Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device)
-        return eng.project(self._state, [Xd], mixed=self._mixed).cpu().numpy()
+        return eng.project(self._state, [Xd], mixed=self._mixed)
+
+    def _project(self, X) -> np.ndarray:
+        return self._project_dev(X).cpu().numpy()
 
     def predict(self, X):
-        return self._project(X) @ self.coef_ @ self.Y_factors[1].T + self.Y_mean      # tpls.py:143
+        return self._predict_from_scores(self._project_dev(X))                          # tpls.py:143
 
     def transform(self, X, Y=None):
         X_scores = self._project(X)

@@ -245,6 +245,10 @@ int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b,
 int cmtfpls_unit_upper_solve_rows_f64(double* M, int64_t I, int ld, int R, const double* U, void* stream);
 int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, double scale, void* stream);
 int cmtfpls_khatri_rao_f64(const double* Am, int na, const double* Bm, int nb, int R, double* out, void* stream);
+/* predict_rows: out[i, m] = mean[m] + sum_a S[i*lds + a] * Bm[a*M + m]: `X_projection @ coef_ @ Q^T + Y_mean` (tpls.py:143,
+ * cmtf.py:177) applied to the device-resident scores, Bm = coef_ Q^T (R x M, formed by the caller); mean nullable. */
+int cmtfpls_predict_rows_f64(const double* S, int64_t I, int lds, int R, const double* Bm, int M, const double* mean,
+                             double* out, int ldo, void* stream);
 int cmtfpls_recon_f32(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
                       const double* mean, float* out, void* stream);
 int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
