@@ -85,9 +85,10 @@ class ctPLS(_EstimatorBase):
         return self._predict_from_scores(self._project_dev(Xs))                         # cmtf.py:177
 
     def transform(self, Xs, Y=None):
-        X_scores = self._project(Xs)
+        scores = self._project_dev(Xs)
+        X_scores = scores.cpu().numpy()
         if Y is not None:
-            return X_scores, self._y_scores(X_scores, Y)
+            return X_scores, self._y_scores(scores, Y)
         return X_scores
 
     def Xs_reconstructed(self, rows=None, device: bool = False):

@@ -121,21 +121,33 @@ class _EstimatorBase(Mapping):
         return scores_dev.cpu().numpy() @ Bm + self.Y_mean
 
     # shared Y-side epilogue of transform (tpls.py:167-184, cmtf.py:212-229) -- host NumPy, I' x M only
-    def _y_scores(self, X_scores: np.ndarray, Y) -> np.ndarray:
-        Y = np.array(Y, dtype=float, copy=True)
+    def _y_scores(self, X_scores, Y) -> np.ndarray:
+        """Y-side epilogue of transform (tpls.py:167-184, cmtf.py:212-229): per component Y_scores[:, a] = Y q_a, then
+        Y -= (X_scores coef_[:, a]) q_a^T.  Runs through the backend's rowdot / y_deflate kernels on the device-resident
+        scores (the host form spends its time starting BLAS threads for I' x 16 products)."""
+        Y = Y.detach().cpu().numpy() if isinstance(Y, torch.Tensor) else np.asarray(Y)
         if (Y.ndim != 1) and (Y.ndim != 2):
             raise ValueError("Only a matrix (2-mode tensor) Y is allowed.")
         if Y.ndim == 1:
             Y = Y.reshape((-1, 1))
         if self.Y_shape[1:] != Y.shape[1:]:
             raise ValueError(f"Training Y has shape {self.Y_shape}, while the new Y has shape {Y.shape}")
-        Y -= self.Y_mean
-        Q = self.Y_factors[1]
-        Y_scores = np.zeros((Y.shape[0], self.n_components))
-        for a in range(self.n_components):
-            Y_scores[:, a] = Y @ Q[:, a]
-            Y -= X_scores @ self.coef_[:, [a]] @ Q[:, [a]].T
-        return Y_scores
+        eng = self._get_engine()
+        be = eng.be
+        R = self.n_components
+        with eng.device_ctx():
+            dev = X_scores.device if isinstance(X_scores, torch.Tensor) else be.device
+            Xs = X_scores if isinstance(X_scores, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X_scores)).to(dev)
+            Yd = torch.from_numpy(np.array(Y, dtype=np.float64, copy=True) - self.Y_mean).to(dev)       # I' x M: small next to X
+            Q = torch.from_numpy(np.ascontiguousarray(self.Y_factors[1].T)).to(dev)                     # row a = q_a
+            C = torch.from_numpy(np.ascontiguousarray(self.coef_.T)).to(dev)                            # row a = coef_[:, a]
+            Y_scores = be.zeros(Yd.shape[0], R)
+            col = be.empty(Yd.shape[0])
+            for a in range(R):
+                be.rowdot(Yd, Q[a], col, None)                                                          # Y @ q_a
+                Y_scores[:, a].copy_(col)
+                be.y_deflate(Yd, Xs, R, C[a], Q[a])                                                     # Y -= (X_scores coef_[:, a]) q_a^T
+            return Y_scores.cpu().numpy()
 
 
 class tPLS(_EstimatorBase):
@@ -207,9 +219,10 @@ class tPLS(_EstimatorBase):
         return self._predict_from_scores(self._project_dev(X))                          # tpls.py:143
 
     def transform(self, X, Y=None):
-        X_scores = self._project(X)
+        scores = self._project_dev(X)
+        X_scores = scores.cpu().numpy()
         if Y is not None:
-            return X_scores, self._y_scores(X_scores, Y)
+            return X_scores, self._y_scores(scores, Y)
         return X_scores
 
     def R2X_literal(self, X):

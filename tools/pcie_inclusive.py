@@ -30,6 +30,8 @@ t, _ = clock(lambda: m.transform(X)); print(f"transform (one MTTKRP pass) device
 t, _ = clock(lambda: m.transform(xh)); print(f"transform host f32 input: {t:.4f} s")
 t, _ = clock(lambda: m.transform(xh64)); print(f"transform host f64 input: {t:.4f} s")
 t, _ = clock(lambda: m.predict(X)); print(f"predict device input: {t:.4f} s")
+m.transform(X, yh)
+t, _ = clock(lambda: m.transform(X, yh)); print(f"transform(X, Y) device X, host Y (Y side through rowdot / y_deflate): {t:.4f} s")
 # where transform's time goes (device input)
 from cmtf_pls_amd.tpls import to_device_copy
 eng = m._get_engine()
