@@ -15,3 +15,12 @@ def test_c_abi_demo_runs():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C ABI demo OK" in out.stdout
+
+
+def test_python_quickstart_runs():
+    """examples/quickstart.py end to end (fit, transform / predict, one-launch LOO, NaN imputation, coupled blocks, xcov)."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "quickstart.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "Q2Y (leave-one-out)" in p.stdout and "ctPLS R2Y" in p.stdout
