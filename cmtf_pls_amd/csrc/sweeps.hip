@@ -560,7 +560,11 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   constexpr int Vp = 16 / (int)sizeof(T);
   const bool vecp = (P % Vp) == 0;
   const bool full4 = vecp && (P % ((int64_t)kSweepThreads * Vp * 4)) == 0, full2 = vecp && (P % ((int64_t)kSweepThreads * Vp * 2)) == 0;
-  const ContractPlan p4 = plan_contract(I, P, (int)sizeof(T), 4, full4 ? kContractBlocksFull : kContractBlocks);
+  // very long rows (>= 16 column tiles of 4 groups, e.g. 256 x 256 f32): one workgroup per CU is best (7.2 against 6.95 TB/s
+  // at 32768 x 256 x 256, profiles/r02t_tune_full.txt)
+  const int64_t tiles4 = vecp ? (P + (int64_t)kSweepThreads * Vp * 4 - 1) / ((int64_t)kSweepThreads * Vp * 4) : 0;
+  const int blocks4 = !full4 ? kContractBlocks : (tiles4 >= 16 ? kContractBlocksFull / 2 : kContractBlocksFull);
+  const ContractPlan p4 = plan_contract(I, P, (int)sizeof(T), 4, blocks4);
   const bool wideU = MODE != 2 && kContractU == 4 && p4.rows_per_block >= 128;
   const ContractPlan p = wideU ? p4 : plan_contract(I, P, (int)sizeof(T), 2, full2 ? kContractBlocksFull : kContractBlocks);
   const bool fullt = wideU ? full4 : full2;
