@@ -563,7 +563,9 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   // very long rows (>= 16 column tiles of 4 groups, e.g. 256 x 256 f32): one workgroup per CU is best (7.2 against 6.95 TB/s
   // at 32768 x 256 x 256, profiles/r02t_tune_full.txt)
   const int64_t tiles4 = vecp ? (P + (int64_t)kSweepThreads * Vp * 4 - 1) / ((int64_t)kSweepThreads * Vp * 4) : 0;
-  const int blocks4 = !full4 ? kContractBlocks : (tiles4 >= 16 ? kContractBlocksFull / 2 : kContractBlocksFull);
+  const bool one_per_cu = tiles4 >= 16 && I * tiles4 <= (int64_t)8192 * (kContractBlocksFull / 2);   // ... while a workgroup's
+  // row block stays <= 8192 rows: at 262144 x 256 x 256, 256 workgroups fall to 6.8 TB/s and 512 hold 7.06 (profiles/r02ad_tune_cfg5.txt)
+  const int blocks4 = !full4 ? kContractBlocks : (one_per_cu ? kContractBlocksFull / 2 : kContractBlocksFull);
   const ContractPlan p4 = plan_contract(I, P, (int)sizeof(T), 4, blocks4);
   const bool wideU = MODE != 2 && kContractU == 4 && p4.rows_per_block >= 128;
   const ContractPlan p = wideU ? p4 : plan_contract(I, P, (int)sizeof(T), 2, full2 ? kContractBlocksFull : kContractBlocks);

@@ -66,6 +66,11 @@ def main():
             rec(f"xcov mixed (M={args.M}, f32 MFMA)", lambda: be.xcov(X, Y, False, out=S, mixed=True), xbytes)
             rec("mttkrp mixed (R=10, f32 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo, mixed=True), xbytes)
         return
+    if args.only == "contract":
+        rec("mode0_contract", lambda: be.mode0_contract(X, u, False, out=Z), xbytes)
+        rec("mode0_contract_yq (u = Y q inside)", lambda: be.mode0_contract_yq(X, Y, q, False, out=Z), xbytes)
+        rec("score", lambda: be.score(X, A, B, wa, wb, None, t), xbytes)
+        return
     # reference point: a plain device copy of X (read + write)
     X2 = torch.empty_like(X)
     rec("torch copy (r+w)", lambda: X2.copy_(X), 2 * xbytes)

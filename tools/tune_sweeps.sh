@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-VARIANTS=("base:" "f1024:-DCMTFPLS_CONTRACT_BLOCKS_FULL=1024" "f768:-DCMTFPLS_CONTRACT_BLOCKS_FULL=768" "f2048:-DCMTFPLS_CONTRACT_BLOCKS_FULL=2048" "f512r4:-DCMTFPLS_UNROLL_FULL=4" "f1024r4:-DCMTFPLS_CONTRACT_BLOCKS_FULL=1024 -DCMTFPLS_UNROLL_FULL=4" "f256:-DCMTFPLS_CONTRACT_BLOCKS_FULL=256")
+VARIANTS=("base:" "f1024:-DCMTFPLS_CONTRACT_BLOCKS_FULL=1024" "f2048:-DCMTFPLS_CONTRACT_BLOCKS_FULL=2048" "f4096:-DCMTFPLS_CONTRACT_BLOCKS_FULL=4096" "f2048r4:-DCMTFPLS_CONTRACT_BLOCKS_FULL=2048 -DCMTFPLS_UNROLL_FULL=4")
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   for v in "${VARIANTS[@]}"; do
@@ -19,6 +19,6 @@ else
   for v in "${VARIANTS[@]}"; do
     name="${v%%:*}"
     echo "=== variant $name"
-    CMTFPLS_LIB="$OUT/libcmtfpls_$name.so" python "$ROOT/tools/kernel_bench.py" --only sweeps "${@:2}" 2>&1 | grep -v amdgpu.ids
+    CMTFPLS_LIB="$OUT/libcmtfpls_$name.so" python "$ROOT/tools/kernel_bench.py" --only "${ONLY:-sweeps}" "${@:2}" 2>&1 | grep -v amdgpu.ids
   done
 fi
