@@ -105,7 +105,15 @@ class _EstimatorBase(Mapping):
             f = [factors[0] if rows is None else factors[0][rows]] + list(factors[1:])
             out = factors_to_tensor(f) + mean
             return torch.from_numpy(out) if device else out
-        return rec if device else rec.cpu().numpy().astype(np.float64)
+        if device:
+            return rec
+        if rec.dtype == torch.float64 or rec.numel() * 8 < (64 << 20):
+            return rec.double().cpu().numpy()
+        out = np.empty(tuple(rec.shape), dtype=np.float64)         # float64 on the host as the reference returns it: widen on the
+        rows = max(1, (256 << 20) // max(rec[0].numel() * 8, 1))   # device row block by row block (a host astype of 4.3 GB costs seconds)
+        for r in range(0, rec.shape[0], rows):
+            out[r:r + rows] = rec[r:r + rows].double().cpu().numpy()
+        return out
 
     def _predict_from_scores(self, scores_dev: torch.Tensor) -> np.ndarray:
         """`X_projection @ coef_ @ Q^T + Y_mean` (tpls.py:143, cmtf.py:177); on the device when the backend has the
