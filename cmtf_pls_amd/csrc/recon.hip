@@ -11,13 +11,14 @@ namespace cmtfpls {
 
 constexpr int kReconMaxR = 16;   // components per pass (register budget); more are accumulated in passes
 
-template <typename T, int RC>
+// VEC false: any shape (B not a multiple of 16 bytes, unaligned output): one element per thread, scalar accesses
+template <typename T, int RC, bool VEC>
 __global__ __launch_bounds__(kSweepThreads) void recon_kernel(const double* __restrict__ Tm, int ldt, int r0, int R,
                                                              const double* __restrict__ WA, const double* __restrict__ WB, int B,
                                                              const double* __restrict__ mean, T* __restrict__ out, int64_t I, int64_t P,
                                                              int rows_per_block, int accumulate) {
-  constexpr int V = VecOf<T>::N;
-  using VT = typename VecOf<T>::type;
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  using VT = Pack<T, V>;
   const int64_t c = ((int64_t)blockIdx.x * kSweepThreads + threadIdx.x) * V;
   if (c >= P) return;
   const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
@@ -58,11 +59,8 @@ template <typename T>
 static int run_recon(const double* Tm, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
                      const double* mean, T* out, hipStream_t st) {
   if (!Tm || !WA || !WB || !out || I <= 0 || R <= 0 || A <= 0 || B <= 0 || ldt < R) { set_error("recon: bad argument"); return CMTFPLS_EINVAL; }
-  constexpr int V = VecOf<T>::N;
-  if ((B % V) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) {
-    set_error("recon: the last-mode product must be a multiple of 16 bytes and the output 16-byte aligned");
-    return CMTFPLS_EUNSUPPORTED;
-  }
+  const bool vec = (B % VecOf<T>::N) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  const int V = vec ? VecOf<T>::N : 1;
   const int64_t P = (int64_t)A * B;
   const int col_tiles = (int)((P / V + kSweepThreads - 1) / kSweepThreads);
   int64_t want = (2048 + col_tiles - 1) / col_tiles;
@@ -70,14 +68,14 @@ static int run_recon(const double* Tm, int64_t I, int ldt, int R, const double* 
   if (rpb < 8) rpb = 8;
   const int row_blocks = (int)((I + rpb - 1) / rpb);
   const dim3 grid(col_tiles, row_blocks), block(kSweepThreads);
+#define RK(RCC, VV) hipLaunchKernelGGL((recon_kernel<T, RCC, VV>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc)
   for (int r0 = 0; r0 < R; r0 += kReconMaxR) {
     const int rc = (R - r0 < kReconMaxR) ? R - r0 : kReconMaxR;
     const int acc = r0 > 0;
-    if (rc <= 4) hipLaunchKernelGGL((recon_kernel<T, 4>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
-    else if (rc <= 8) hipLaunchKernelGGL((recon_kernel<T, 8>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
-    else if (rc <= 12) hipLaunchKernelGGL((recon_kernel<T, 12>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
-    else hipLaunchKernelGGL((recon_kernel<T, 16>), grid, block, 0, st, Tm, ldt, r0, R, WA, WB, B, mean, out, I, P, (int)rpb, acc);
+    if (vec) { if (rc <= 4) RK(4, true); else if (rc <= 8) RK(8, true); else if (rc <= 12) RK(12, true); else RK(16, true); }
+    else     { if (rc <= 4) RK(4, false); else if (rc <= 8) RK(8, false); else if (rc <= 12) RK(12, false); else RK(16, false); }
   }
+#undef RK
   return check_launch("recon");
 }
 
@@ -85,14 +83,14 @@ static int run_recon(const double* Tm, int64_t I, int ldt, int R, const double* 
 //   part[blk][0] = sum over finite x of (xhat - x)^2,   part[blk][1] = sum over finite x of x^2,
 // x = X[i, c] - mean[c] (the centred original, tpls.py:115-117), xhat = sum_r T[i, r] WA[c / B, r] WB[c % B, r].
 // One read of X; same thread layout as recon_kernel.
-template <typename T, int RC>
+template <typename T, int RC, bool VEC>
 __global__ __launch_bounds__(kSweepThreads) void recon_r2_kernel(const T* __restrict__ X, const double* __restrict__ Tm, int ldt, int R,
                                                                 const double* __restrict__ WA, const double* __restrict__ WB, int B,
                                                                 const double* __restrict__ mean, int64_t I, int64_t P, int rows_per_block,
                                                                 double* __restrict__ part) {
   __shared__ double red[16];
-  constexpr int V = VecOf<T>::N;
-  using VT = typename VecOf<T>::type;
+  constexpr int V = VEC ? VecOf<T>::N : 1;
+  using VT = Pack<T, V>;
   const int64_t c = ((int64_t)blockIdx.x * kSweepThreads + threadIdx.x) * V;
   const bool live = c < P;
   const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
@@ -154,11 +152,9 @@ template <typename T>
 static int run_recon_r2(const T* X, const double* Tm, int64_t I, int ldt, int R, const double* WA, const double* WB, int A, int B,
                         const double* mean, double* out, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!X || !Tm || !WA || !WB || !out || I <= 0 || R <= 0 || A <= 0 || B <= 0 || ldt < R) { set_error("recon_r2: bad argument"); return CMTFPLS_EINVAL; }
-  constexpr int V = VecOf<T>::N;
-  if ((B % V) != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || R > kReconMaxR) {
-    set_error("recon_r2: needs B % (16/sizeof(T)) == 0, a 16-byte aligned X and R <= 16");
-    return CMTFPLS_EUNSUPPORTED;
-  }
+  if (R > kReconMaxR) { set_error("recon_r2: more than 16 components"); return CMTFPLS_EUNSUPPORTED; }
+  const bool vec = (B % VecOf<T>::N) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  const int V = vec ? VecOf<T>::N : 1;
   const int64_t P = (int64_t)A * B;
   int col_tiles, row_blocks;
   int64_t rpb;
@@ -167,10 +163,10 @@ static int run_recon_r2(const T* X, const double* Tm, int64_t I, int ldt, int R,
   if (!ws || ws_bytes < nblk * 2 * sizeof(double)) { set_error("recon_r2: workspace too small"); return CMTFPLS_EWORKSPACE; }
   double* part = static_cast<double*>(ws);
   const dim3 grid(col_tiles, row_blocks), block(kSweepThreads);
-  if (R <= 4) hipLaunchKernelGGL((recon_r2_kernel<T, 4>), grid, block, 0, st, X, Tm, ldt, R, WA, WB, B, mean, I, P, (int)rpb, part);
-  else if (R <= 8) hipLaunchKernelGGL((recon_r2_kernel<T, 8>), grid, block, 0, st, X, Tm, ldt, R, WA, WB, B, mean, I, P, (int)rpb, part);
-  else if (R <= 12) hipLaunchKernelGGL((recon_r2_kernel<T, 12>), grid, block, 0, st, X, Tm, ldt, R, WA, WB, B, mean, I, P, (int)rpb, part);
-  else hipLaunchKernelGGL((recon_r2_kernel<T, 16>), grid, block, 0, st, X, Tm, ldt, R, WA, WB, B, mean, I, P, (int)rpb, part);
+#define R2K(RCC, VV) hipLaunchKernelGGL((recon_r2_kernel<T, RCC, VV>), grid, block, 0, st, X, Tm, ldt, R, WA, WB, B, mean, I, P, (int)rpb, part)
+  if (vec) { if (R <= 4) R2K(4, true); else if (R <= 8) R2K(8, true); else if (R <= 12) R2K(12, true); else R2K(16, true); }
+  else     { if (R <= 4) R2K(4, false); else if (R <= 8) R2K(8, false); else if (R <= 12) R2K(12, false); else R2K(16, false); }
+#undef R2K
   launch_reduce_rows(part, (int)nblk, 2, out, st);
   return check_launch("recon_r2");
 }
@@ -191,7 +187,7 @@ int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* 
 size_t cmtfpls_recon_r2_workspace_bytes(int64_t I, int64_t P) {
   if (I <= 0 || P <= 0) return 0;
   size_t most = 0;
-  for (int V = 2; V <= 4; V += 2) {
+  for (int V = 1; V <= 4; V *= 2) {
     int ct, rb;
     int64_t rpb;
     recon_r2_plan(I, P, V, &ct, &rb, &rpb);

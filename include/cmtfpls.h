@@ -240,7 +240,8 @@ int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
  *   (tensorly.tenalg.khatri_rao as used by util.py:19, first matrix varying slowest).
  * recon: Xhat[i, c] = sum_r T[i*ldt + r] * WA[(c / B)*R + r] * WB[(c % B)*R + r] + mean[c]  for I rows, written
  *   in the storage type: factors_to_tensor (util.py:18-20) + X_mean as X_reconstructed uses it (tpls.py:188-189,
- *   cmtf.py:233-237), the Khatri-Rao operand never materialised; mean nullable.  B % (16/sizeof(T)) == 0. */
+ *   cmtf.py:233-237), the Khatri-Rao operand never materialised; mean nullable.  Any shape (16-byte vectors when
+ *   B % (16/sizeof(T)) == 0 and `out` is aligned, single elements otherwise). */
 int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b, int incb, void* stream);
 int cmtfpls_unit_upper_solve_rows_f64(double* M, int64_t I, int ld, int R, const double* U, void* stream);
 int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, double scale, void* stream);
@@ -257,7 +258,7 @@ int cmtfpls_recon_f64(const double* T, int64_t I, int ldt, int R, const double* 
  * cmtf.py:132-134) in ONE read of the original X, the reconstruction never materialised:
  *   out[0] = sum over finite x of (xhat - x)^2,  out[1] = sum over finite x of x^2,  x = X[i,c] - mean[c] (mean
  * nullable), xhat as in recon;  R2X = 1 - out[0] / out[1].  (The fit itself gets R2X from the deflation sweep; this
- * is the literal formula for callers of calcR2X and for checking that identity at full size.)  R <= 16. */
+ * is the literal formula for callers of calcR2X and for checking that identity at full size.)  Any shape; R <= 16. */
 size_t cmtfpls_recon_r2_workspace_bytes(int64_t I, int64_t P);
 int cmtfpls_recon_r2_f32(const float* X, const double* T, int64_t I, int ldt, int R, const double* WA, const double* WB,
                          int A, int B, const double* mean, double* out, void* ws, size_t ws_bytes, void* stream);

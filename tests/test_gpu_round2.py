@@ -152,7 +152,7 @@ def test_projection_fixup_kernels(be):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("shape,R", [((40, 12, 16), 3), ((33, 20), 4), ((17, 6, 4, 8), 2), ((25, 8, 8), 19)])
+@pytest.mark.parametrize("shape,R", [((40, 12, 16), 3), ((33, 20), 4), ((17, 6, 4, 8), 2), ((25, 8, 8), 19), ((21, 5, 7), 3), ((19, 13), 2)])
 def test_reconstruction_on_device_matches_oracle(shape, R, dtype):
     """X_reconstructed (tpls.py:188-189) = factors_to_tensor (util.py:18-20) + X_mean through cmtfpls_recon_*."""
     from cmtf_pls_amd import tPLS
@@ -278,7 +278,7 @@ def test_loo_declines_shapes_outside_its_form():
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("shape,nan", [((60, 12, 16), 0.0), ((50, 12, 16), 0.25), ((40, 24), 0.0), ((30, 6, 4, 8), 0.0)])
+@pytest.mark.parametrize("shape,nan", [((60, 12, 16), 0.0), ((50, 12, 16), 0.25), ((40, 24), 0.0), ((30, 6, 4, 8), 0.0), ((30, 5, 7), 0.1)])
 def test_literal_r2x_on_device_equals_the_deflation_identity(shape, nan, dtype):
     """calcR2X(X_c, factors_to_tensor(X_factors)) (util.py:7-15, tpls.py:115-117) through cmtfpls_recon_r2_* == the R2X the
     fit books from the deflation sweep == the oracle's literal formula."""
