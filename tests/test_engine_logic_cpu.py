@@ -124,6 +124,13 @@ def test_no_cpu_fallback_in_product_path():
     x, y, _ = O.import_synthetic((10, 4, 3), 2, 2)
     with pytest.raises(_lib.CmtfplsError):
         tPLS(2).fit(x, y)                                      # no GPU here -> must fail loudly
+    from cmtf_pls_amd.missingvals import miss_mmodedot, miss_tensordot
+    with pytest.raises(_lib.CmtfplsError):
+        miss_tensordot(x, y[:, 0])                             # the missing-value contractions too
+    with pytest.raises(_lib.CmtfplsError):
+        miss_mmodedot(x, [np.ones(4), np.ones(3)])
+    with pytest.raises(AssertionError):
+        miss_tensordot(x, y[:5, 0])                            # missingvals.py:10: sample counts must agree
 
 
 @pytest.mark.parametrize("shape", [(20, 8, 6, 4), (12, 5, 4, 3, 2)])
