@@ -36,24 +36,33 @@ typedef double d4m_t __attribute__((ext_vector_type(4)));
 #define CMTFPLS_MTTKRP_UN 4
 #endif
 
+// The loadings of both modes, padded to 16 components, must fit one workgroup's LDS: (A + B) * 16 * ceil(R / 16) doubles.
+// Up to 64 KB two or more workgroups share a CU; beyond that one workgroup per CU (152 KB: A + B <= 1216 at R <= 16), which
+// still beats the R read+write passes of the sequential path by a wide margin (profiles/r02an_mttkrp_big_lds.txt).
+constexpr size_t kMttkrpLdsMax = 152 * 1024;
+
 // FAST: I % 16 == 0 and P % (16 * UN) == 0 with vector loads: no clamps, no selects.
-template <typename T, bool VEC, int RT, bool FAST>
-__global__ __launch_bounds__(256) void mttkrp_kernel(const T* __restrict__ X, int64_t I, int A, int B,
+// NT threads per workgroup: the loadings are staged once per workgroup, so a workgroup whose LDS share allows only one or
+// two of its kind per CU brings 8 or 16 wavefronts instead of 4 (every wavefront works on its own 16 rows: the result
+// does not depend on NT).
+template <typename T, bool VEC, int RT, bool FAST, int NT>
+__global__ __launch_bounds__(NT) void mttkrp_kernel(const T* __restrict__ X, int64_t I, int A, int B,
                                                     const double* __restrict__ WA, const double* __restrict__ WB, int R,
                                                     double* __restrict__ out, int ldo) {
   extern __shared__ double lds[];          // sA[A][16*RT] then sB[B][16*RT], zero padded beyond R
   constexpr int RP = 16 * RT;
   double* sA = lds;
   double* sB = lds + (size_t)A * RP;
-  for (int idx = threadIdx.x; idx < A * RP; idx += 256) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
-  for (int idx = threadIdx.x; idx < B * RP; idx += 256) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
+  constexpr int NW = NT / 64;
+  for (int idx = threadIdx.x; idx < A * RP; idx += NT) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
+  for (int idx = threadIdx.x; idx < B * RP; idx += NT) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ri = lane & 15, kq = lane >> 4;
   const int64_t P = (int64_t)A * B;
   const int64_t ngroups = (I + 15) / 16;
   using XV = Pack<T, 4>;
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wv; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+  for (int64_t grp = (int64_t)blockIdx.x * NW + wv; grp < ngroups; grp += (int64_t)gridDim.x * NW) {
     const int64_t i0 = grp * 16;
     const bool rok = FAST || (i0 + ri) < I;
     const T* __restrict__ xr = X + ((rok ? i0 + ri : I - 1)) * P;
@@ -112,17 +121,42 @@ static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, con
   if (R > 32) { set_error("mttkrp: more than 32 components per call"); return CMTFPLS_EUNSUPPORTED; }
   const int rt = (R + 15) / 16;
   const size_t lds = (size_t)(A + B) * 16 * rt * sizeof(double);
-  if (lds > 96 * 1024) { set_error("mttkrp: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
+  if (lds > kMttkrpLdsMax) { set_error("mttkrp: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
   const bool vec = (B % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) == 0);
   const int64_t ngroups = (I + 15) / 16;
-  int grid = (int)((ngroups + 3) / 4);
-  if (grid > 2048) grid = 2048;
-  const dim3 g(grid), b(256);
+  // Threads per workgroup (profiles/r02ap_mttkrp_nt.txt): the LDS share decides how many workgroups a CU holds; take the
+  // smallest workgroup that still puts 16 wavefronts on a CU (64 KB of loadings at 256 x 256: 512 threads, 4.8 -> 5.4 TB/s;
+  // 96 KB: 3.1 -> 4.8 TB/s), but never so large that fewer than 256 workgroups are left for the 256 CUs (few, long rows).
+#ifdef CMTFPLS_MTTKRP_NT
+  const int nt = vec ? CMTFPLS_MTTKRP_NT : 256;                  // tuning builds only
+#else
+  int nt = 256;
+  if (vec) {
+    const int wgs_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    while (nt < 1024 && wgs_per_cu * (nt / 64) < 16) nt *= 2;
+    while (nt > 256 && (ngroups + nt / 64 - 1) / (nt / 64) < 256) nt /= 2;
+  }
+#endif
+  const int nw = nt / 64;
+  int grid = (int)((ngroups + nw - 1) / nw);
+  if (grid > 8192 / nw) grid = 8192 / nw;
+  const dim3 g(grid), b(nt);
   const bool fast = vec && (I % 16 == 0) && (((int64_t)A * B) % (16 * CMTFPLS_MTTKRP_UN) == 0);
-#define ML(VC, RTT, FS) hipLaunchKernelGGL((mttkrp_kernel<T, VC, RTT, FS>), g, b, lds, st, X, I, A, B, WA, WB, R, out, ldo)
-  if (fast) { if (rt == 1) ML(true, 1, true); else ML(true, 2, true); }
-  else if (vec) { if (rt == 1) ML(true, 1, false); else ML(true, 2, false); }
-  else     { if (rt == 1) ML(false, 1, false); else ML(false, 2, false); }
+#define ML(VC, RTT, FS, NTT)                                                                                                   \
+  do {                                                                                                                         \
+    if (lds > 64 * 1024)                                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mttkrp_kernel<T, VC, RTT, FS, NTT>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+    hipLaunchKernelGGL((mttkrp_kernel<T, VC, RTT, FS, NTT>), g, b, lds, st, X, I, A, B, WA, WB, R, out, ldo);                  \
+  } while (0)
+#define MLN(RTT, FS)                                                                                                           \
+  do {                                                                                                                         \
+    if (nt == 256) ML(true, RTT, FS, 256); else if (nt == 512) ML(true, RTT, FS, 512); else ML(true, RTT, FS, 1024);           \
+  } while (0)
+  if (fast) { if (rt == 1) MLN(1, true); else MLN(2, true); }
+  else if (vec) { if (rt == 1) MLN(1, false); else MLN(2, false); }
+  else     { if (rt == 1) ML(false, 1, false, 256); else ML(false, 2, false, 256); }
+#undef MLN
 #undef ML
   return check_launch("mttkrp");
 }

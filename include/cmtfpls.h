@@ -142,7 +142,8 @@ int cmtfpls_mttkrp_f32_mixed(const float* X, int64_t I, int A, int B, const doub
  * WA (A x R) and WB (B x R) row-major f64, R <= 32, on the f64 matrix cores with the Khatri-Rao
  * operand formed on the fly in LDS.  One pass over X replaces the R project-and-deflate passes of
  * predict / transform (tpls.py:133-142, 156-165) when X has no NaN:
- * T = M (I + triu(W^T W, 1))^{-1} (the R x R part is done by the caller). */
+ * T = M (I + triu(W^T W, 1))^{-1} (the R x R part is done by the caller).
+ * CMTFPLS_EUNSUPPORTED when R > 32 or (A + B) * 16 * ceil(R / 16) doubles exceed 152 KB of LDS. */
 int cmtfpls_mttkrp_f32(const float* X, int64_t I, int A, int B, const double* WA, const double* WB, int R,
                        double* out, int ldo, void* stream);
 int cmtfpls_mttkrp_f64(const double* X, int64_t I, int A, int B, const double* WA, const double* WB, int R,

@@ -178,3 +178,28 @@ def test_cfg5_full_size_properties(api):
     rec = torch.einsum("ir,jr,kr->ijk", Tsub, torch.from_numpy(m.X_factors[1]).cuda(), torch.from_numpy(m.X_factors[2]).cuda())
     r2_sample = 1 - float(((Xs - rec) ** 2).sum()) / float((Xs ** 2).sum())
     assert abs(r2_sample - m.R2X[-1]) < 1e-2
+
+
+# ---- trailing modes beyond every BASELINE config: rows of 196 608 - 655 360 elements -----------------
+@pytest.mark.parametrize("shape,M,dt", [((48, 512, 384), 5, "float32"), ((24, 1024, 640), 3, "float64")])
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_very_long_rows_fit_vs_oracle(api, shape, M, dt, algorithm):
+    """Rows of 0.75 - 5 MB (several 1024-thread segments per row in the row-per-workgroup sweeps, the loadings
+    read from global memory where they exceed the LDS, rank-1 extraction at n = 384 / 640 up to its 1024 limit).
+    transform / predict: at 512 x 384 the one-pass MTTKRP with 112 KB of loadings in LDS (one workgroup per CU); at
+    1024 x 640 the loadings (208 KB) exceed the MTTKRP's LDS budget, which the engine must notice by itself and
+    take the SEQUENTIAL project-and-deflate path."""
+    x, y, _ = O.import_synthetic(shape, M, 3, error=0.1, seed=31)
+    if dt == "float32":
+        x, y = _f32(x), _f32(y)
+    fit = O.fit_tpls(x, y, 2, max_iter=25)
+    m = api.tPLS(2, dtype=dt, algorithm=algorithm)
+    m.fit(x, y, max_iter=25)
+    check_fit(m, fit, rtol=RTOL if dt == "float32" else 1e-7)
+    T = m.transform(x[:16])
+    col_close(T, O.transform(fit, x[:16]), RTOL if dt == "float32" else 1e-7)
+    col_close(m.predict(x[:16]), O.predict(fit, x[:16]), RTOL if dt == "float32" else 1e-7)
+    xr = m.X_reconstructed()
+    assert xr.shape == shape
+    want = O.reconstruct(fit)
+    assert_allclose(xr, want, rtol=0, atol=(1e-4 if dt == "float32" else 1e-6) * np.abs(want).max())

@@ -1,7 +1,8 @@
 """Randomised shapes through every X kernel against NumPy float64: ragged rows/columns, B not a
 multiple of the vector width, P below one wavefront, exact-cover shapes that select the guard-free
 specialisations (score_deflate KC/FULL, xcov/mttkrp FAST), both storage types, with and without NaNs.
-Seeded: the same 48 cases every run.
+Seeded: the same 54 cases every run (the last six: rows of 24 000 - 1 048 576 elements, trailing modes up to the
+rank-1 kernels' limit of 1024).
 """
 import numpy as np
 import pytest
@@ -21,7 +22,7 @@ def _cases():
     rng = np.random.default_rng(2024)
     special = [(1, 1, 1), (2, 1, 3), (3, 2, 2), (5, 1, 64), (16, 4, 4), (17, 16, 16), (33, 64, 4), (64, 8, 32),
                (96, 128, 128), (40, 256, 64), (48, 64, 256), (31, 3, 100), (130, 1, 1024), (70, 33, 31), (19, 2, 514),
-               (256, 16, 64)]
+               (256, 16, 64), (12, 512, 512), (6, 1024, 1024), (9, 1000, 24), (7, 24, 1000), (20, 512, 128), (32, 128, 640)]
     cases = []
     for i, (I, A, B) in enumerate(special):
         cases.append((I, A, B, "f32" if i % 2 == 0 else "f64", i % 3 == 0))
@@ -74,7 +75,10 @@ def test_random_shape(be, I, A, B, dt, masked):
         R = int(rng.integers(1, 20))
         WA, WB = rng.normal(size=(A, R)), rng.normal(size=(B, R))
         out = be.mttkrp(X, A, B, dev(WA), dev(WB), be.empty(I, R))
-        np.testing.assert_allclose(host(out), x @ (WA[:, None, :] * WB[None, :, :]).reshape(P, R), **tol)
+        if out is None:                                        # loadings beyond the LDS: the engine projects sequentially
+            assert (A + B) * (R + (-R) % 16) * 8 > 96 * 1024 or R > 32
+        else:
+            np.testing.assert_allclose(host(out), x @ (WA[:, None, :] * WB[None, :, :]).reshape(P, R), **tol)
     # fused score + deflate, then plain deflate on a second copy
     t_safe = np.nan_to_num(t_want)
     X1 = dev(x, TDT[dt])
