@@ -284,11 +284,16 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_normal_solve_f64(_ptr(G), _ptr(g), k, _ptr(b), 1, self._stream()), "normal_solve")
         return b
 
-    def unit_upper_solve_rows(self, M: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
-        """Rows of M (I x R) overwritten by the rows of T solving T (I + triu(U, 1)) = M."""
+    def unit_upper_solve_rows(self, M: torch.Tensor, U: torch.Tensor, shift: Optional[torch.Tensor] = None,
+                              nan_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Rows of M (I x R) overwritten by the rows of T solving T (I + triu(U, 1)) = M - 1 shift^T; nan_flag (one int32,
+        zeroed by the caller) is set when M holds a NaN."""
         I, R = M.shape
         assert M.stride(1) == 1 and U.is_contiguous() and U.shape == (R, R)
-        _lib.check(self.lib.cmtfpls_unit_upper_solve_rows_f64(_ptr(M), I, M.stride(0), R, _ptr(U), self._stream()), "unit_upper_solve_rows")
+        assert shift is None or (shift.is_contiguous() and shift.numel() == R and shift.dtype == torch.float64)
+        assert nan_flag is None or nan_flag.dtype == torch.int32
+        _lib.check(self.lib.cmtfpls_unit_upper_solve_rows_f64(_ptr(M), I, M.stride(0), R, _ptr(U), _ptr(shift), _ptr(nan_flag),
+                                                              self._stream()), "unit_upper_solve_rows")
         return M
 
     def kr_gram(self, L: torch.Tensor, G: torch.Tensor, first: bool) -> torch.Tensor:

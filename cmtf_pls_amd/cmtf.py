@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .tpls import _EstimatorBase, _as_torch_dtype, to_device_copy
+from .tpls import _EstimatorBase, _as_torch_dtype, _project_blocks, to_device_copy
 
 
 class ctPLS(_EstimatorBase):
@@ -75,8 +75,7 @@ class ctPLS(_EstimatorBase):
                     f"Training X[{ti}] has shape {self.Xs_shape[ti]}, while the new X has shape {tuple(X.shape)}"
                 )
         eng = self._get_engine()
-        Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device) for X in Xs]
-        return eng.project(self._state, Xd, mixed=self._mixed)
+        return _project_blocks(eng, self._state, list(Xs), [_as_torch_dtype(self._dtype, X) for X in Xs], self._mixed)
 
     def _project(self, Xs) -> np.ndarray:
         return self._project_dev(Xs).cpu().numpy()

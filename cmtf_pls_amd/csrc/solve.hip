@@ -72,21 +72,32 @@ __global__ __launch_bounds__(kSolveMax) void normal_solve_kernel(const double* _
   if (i < k) b[(int64_t)i * incb] = y[i] * d[i];
 }
 
-// rows of T solve  T (I + triu(U, 1)) = M:  t_a = m_a - sum_{j < a} t_j U[j][a]   (one thread per row, in place)
+// rows of T solve  T (I + triu(U, 1)) = M - 1 shift^T:  t_a = (m_a - shift_a) - sum_{j < a} t_j U[j][a]   (one thread per
+// row, in place).  shift (R, nullable): the centring of an UNCENTRED MTTKRP, (X - 1 mean^T) W = X W - 1 (mean^T W)^T, so
+// that transform / predict read the caller's X once and never write a centred copy.  nan_flag (nullable, zeroed by the
+// caller): set to 1 when any entry of M is NaN -- a missing value somewhere in that row of X (NaN survives every product
+// and sum), which tells the caller to take the masked sequential path instead.
 __global__ __launch_bounds__(256) void unit_upper_solve_rows_kernel(double* __restrict__ Mx, int64_t I, int ld, int R,
-                                                                   const double* __restrict__ U) {
+                                                                   const double* __restrict__ U, const double* __restrict__ shift,
+                                                                   int* __restrict__ nan_flag) {
   __shared__ double Us[kSolveMax * kSolveMax];
+  __shared__ double sh[kSolveMax];
   for (int idx = threadIdx.x; idx < R * R; idx += 256) Us[idx] = U[idx];
+  for (int idx = threadIdx.x; idx < R; idx += 256) sh[idx] = shift ? shift[idx] : 0.0;
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= I) return;
   double* row = Mx + i * ld;                 // t_j (j < a) is read back from the row this thread just wrote
+  bool bad = false;
 #pragma unroll 1
   for (int a = 0; a < R; ++a) {
     double s = row[a];
+    bad |= (s != s);
+    s -= sh[a];
     for (int j = 0; j < a; ++j) s -= row[j] * Us[j * R + a];
     row[a] = s;
   }
+  if (bad && nan_flag) *nan_flag = 1;        // every writer stores the same value
 }
 
 // G[r][s] = (first ? 1 : G[r][s]) * scale * sum_j L[j][r] L[j][s]     (L: n x R row-major; one workgroup)
@@ -141,10 +152,12 @@ int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b,
   return check_launch("normal_solve");
 }
 
-int cmtfpls_unit_upper_solve_rows_f64(double* Mx, int64_t I, int ld, int R, const double* U, void* stream) {
+int cmtfpls_unit_upper_solve_rows_f64(double* Mx, int64_t I, int ld, int R, const double* U, const double* shift, int* nan_flag,
+                                      void* stream) {
   if (!Mx || !U || I <= 0 || R <= 0 || ld < R) { set_error("unit_upper_solve_rows: bad argument"); return CMTFPLS_EINVAL; }
   if (R > kSolveMax) { set_error("unit_upper_solve_rows: more than 64 components"); return CMTFPLS_EUNSUPPORTED; }
-  hipLaunchKernelGGL(unit_upper_solve_rows_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Mx, I, ld, R, U);
+  hipLaunchKernelGGL(unit_upper_solve_rows_kernel, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Mx, I, ld, R, U,
+                     shift, nan_flag);
   return check_launch("unit_upper_solve_rows");
 }
 

@@ -201,6 +201,21 @@ class NipalsEngine:
         with self.device_ctx():
             return self._project(state, Xs, one_pass, mixed)
 
+    def project_readonly(self, state: FitState, Xs: List[torch.Tensor]) -> Optional[torch.Tensor]:
+        """Scores of new samples from ONE read of every block, the blocks neither copied nor written: the MTTKRP runs on
+        the UNCENTRED rows and the centring `X - X_mean` (tpls.py:130,153; cmtf.py:150,187) is applied to its I x R output,
+        (X - 1 mean^T) W = X W - 1 (mean^T W)^T.  None when this form does not apply -- a missing value anywhere in Xs
+        (seen as a NaN in the MTTKRP output), a training column without observations (NaN mean), a shape the MTTKRP does
+        not take -- and the caller then runs `project` on private copies."""
+        with self.device_ctx():
+            if any(bool(torch.isnan(blk.mean).any().item()) for blk in state.blocks):
+                return None
+            flag = torch.zeros(1, dtype=torch.int32, device=self.be.device)
+            scores = self._project_one_pass(state, Xs, False, centred=False, nan_flag=flag)
+            if scores is None or int(flag.item()) != 0:
+                return None
+            return scores
+
     def _project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool, mixed: bool) -> torch.Tensor:
         be = self.be
         R = state.n_components
@@ -290,8 +305,10 @@ class NipalsEngine:
             res, ssq = self.comm.allreduce(out).cpu().tolist()
             return 1.0 - res / ssq
 
-    def _project_one_pass(self, state: FitState, Xs: List[torch.Tensor], mixed: bool = False) -> Optional[torch.Tensor]:
-        """All R scores from ONE read of every (already centred, NaN-free) block.
+    def _project_one_pass(self, state: FitState, Xs: List[torch.Tensor], mixed: bool = False, centred: bool = True,
+                          nan_flag: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """All R scores from ONE read of every NaN-free block (centred: already centred in place; otherwise the centring
+        is applied to the MTTKRP output as the shift mean^T W, itself an MTTKRP of the one-row "tensor" mean).
 
         The deflations are linear without missing values: X_{b,a+1} = X_{b,a} - t_a w_{b,a}^T with the
         (block-averaged) score t_a, hence X_{b,a} w_{b,a} = M_b[:, a] - sum_{j<a} t_j G_b[j, a] where
@@ -306,16 +323,22 @@ class NipalsEngine:
             return None
         Ms = be.empty(nb, I * R)
         Gs = be.empty(nb, R * R)
+        shifts = None if centred else be.empty(nb, R)
         for b, (blk, X) in enumerate(zip(state.blocks, Xs)):
             loads = blk.loadings
             WA, WB = self._kr_operands(blk, R)
             if be.mttkrp(X.view(I, -1), blk.A, blk.B, WA, WB, Ms[b].view(I, R), mixed=mixed) is None:
                 return None
+            if not centred and be.mttkrp(blk.mean.view(1, -1), blk.A, blk.B, WA, WB, shifts[b].view(1, R)) is None:
+                return None
             for m, L in enumerate(loads):                 # Gram of a Khatri-Rao product = Hadamard product of the mode Grams
                 be.kr_gram(L, Gs[b], first=(m == 0))
         Mbar = be.scores_mean(Ms, be.empty(I * R)).view(I, R) if nb > 1 else Ms[0].view(I, R)
         Gbar = be.scores_mean(Gs, be.empty(R * R)).view(R, R) if nb > 1 else Gs[0].view(R, R)
-        return be.unit_upper_solve_rows(Mbar, Gbar)             # T (I + triu(Gbar, 1)) = Mbar, on the device
+        if centred:
+            return be.unit_upper_solve_rows(Mbar, Gbar, None, nan_flag)      # T (I + triu(Gbar, 1)) = Mbar, on the device
+        shift = be.scores_mean(shifts, be.empty(R)) if nb > 1 else shifts[0]
+        return be.unit_upper_solve_rows(Mbar, Gbar, shift, nan_flag)
 
 
 class FitRun:

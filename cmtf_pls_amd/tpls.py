@@ -58,6 +58,21 @@ def to_device_copy(X, dtype: torch.dtype, device, copy: bool = True) -> torch.Te
     return out
 
 
+def _project_blocks(eng: NipalsEngine, state, Xs, dtypes, mixed: bool) -> torch.Tensor:
+    """Scores of new samples (tpls.py:128-142; cmtf.py:143-177).  First the read-only one-pass form on the blocks as
+    they are (a device tensor of the storage type is not even copied; a host array is uploaded, not centred); where
+    that does not apply (missing values, f32 matrix precision, shapes outside the MTTKRP) the sequential
+    project-and-deflate on private copies, which it centres and deflates in place."""
+    dev = eng.be.device
+    Xd = [to_device_copy(X, dt, dev, copy=False) for X, dt in zip(Xs, dtypes)]
+    if not mixed:
+        scores = eng.project_readonly(state, Xd)
+        if scores is not None:
+            return scores
+    Xd = [xd.clone() if xd is X else xd for xd, X in zip(Xd, Xs)]        # never touch the caller's tensor
+    return eng.project(state, Xd, mixed=mixed)
+
+
 class _EstimatorBase(Mapping):
     def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None,
                  algorithm: str = "direct", graphs: bool = False, matrix_precision: str = "f64", copy_X: bool = True):
@@ -217,8 +232,7 @@ class tPLS(_EstimatorBase):
         if self.X_shape[1:] != tuple(X.shape[1:]):
             raise ValueError(f"Training X has shape {self.X_shape}, while the new X has shape {tuple(X.shape)}")
         eng = self._get_engine()
-        Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), eng.be.device)
-        return eng.project(self._state, [Xd], mixed=self._mixed)
+        return _project_blocks(eng, self._state, [X], [_as_torch_dtype(self._dtype, X)], self._mixed)
 
     def _project(self, X) -> np.ndarray:
         return self._project_dev(X).cpu().numpy()

@@ -234,7 +234,10 @@ int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
  *   diag(G)^(-1/2) G diag(G)^(-1/2) (the score columns differ in scale by orders of magnitude; the raw normal
  *   equations would square that spread); a column that is zero or dependent to working precision gets b = 0.
  * unit_upper_solve_rows: rows of M (I x R, leading dim ld) are overwritten by the rows of T solving
- *   T (I + triu(U, 1)) = M: the R x R part of the one-pass transform / predict (see cmtfpls_mttkrp_*).
+ *   T (I + triu(U, 1)) = M - 1 shift^T: the R x R part of the one-pass transform / predict (see cmtfpls_mttkrp_*).
+ *   shift (R doubles, nullable = 0): mean^T W, the centring `X - X_mean` of tpls.py:130,153 moved behind the MTTKRP,
+ *   (X - 1 mean^T) W = X W - 1 (mean^T W)^T, so that X is read once, uncentred, and never written.  nan_flag (one
+ *   int, nullable, zeroed by the caller): set to 1 when M holds a NaN, i.e. a row of X had a missing value.
  * kr_gram: G (R x R) = (first ? 1 : G) .* scale * L^T L for one loading matrix L (n x R row-major): the Gram
  *   matrix of a Khatri-Rao product is the Hadamard product of the mode Grams; call once per mode.
  * khatri_rao: out ((na * nb) x R) = column-wise Kronecker product of Am (na x R) and Bm (nb x R)
@@ -244,7 +247,8 @@ int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
  *   cmtf.py:233-237), the Khatri-Rao operand never materialised; mean nullable.  Any shape (16-byte vectors when
  *   B % (16/sizeof(T)) == 0 and `out` is aligned, single elements otherwise). */
 int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b, int incb, void* stream);
-int cmtfpls_unit_upper_solve_rows_f64(double* M, int64_t I, int ld, int R, const double* U, void* stream);
+int cmtfpls_unit_upper_solve_rows_f64(double* M, int64_t I, int ld, int R, const double* U, const double* shift, int* nan_flag,
+                                      void* stream);
 int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, double scale, void* stream);
 int cmtfpls_khatri_rao_f64(const double* Am, int na, const double* Bm, int nb, int R, double* out, void* stream);
 /* predict_rows: out[i, m] = mean[m] + sum_a S[i*lds + a] * Bm[a*M + m]: `X_projection @ coef_ @ Q^T + Y_mean` (tpls.py:143,

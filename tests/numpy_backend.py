@@ -195,10 +195,15 @@ class NumpyBackend:
             return out
         return b
 
-    def unit_upper_solve_rows(self, M, U):
+    def unit_upper_solve_rows(self, M, U, shift=None, nan_flag=None):
         R = M.shape[1]
         tri = np.eye(R) + np.triu(_np(U), 1)
-        M.copy_(torch.from_numpy(np.ascontiguousarray(np.linalg.solve(tri.T, _np(M).T).T)))
+        m = _np(M).copy()
+        if nan_flag is not None and np.isnan(m).any():
+            nan_flag.fill_(1)
+        if shift is not None:
+            m = m - _np(shift)[None, :]
+        M.copy_(torch.from_numpy(np.ascontiguousarray(np.linalg.solve(tri.T, m.T).T)))
         return M
 
     def kr_gram(self, L, G, first):

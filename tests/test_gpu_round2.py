@@ -142,6 +142,16 @@ def test_projection_fixup_kernels(be):
     want = np.linalg.solve((np.eye(R) + np.triu(U, 1)).T, M.T).T
     got = be.unit_upper_solve_rows(_dev(M), _dev(U)).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    # with the centring shift of an uncentred MTTKRP and the missing-value flag
+    shift = rng.normal(size=R)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    got = be.unit_upper_solve_rows(_dev(M), _dev(U), _dev(shift), flag).cpu().numpy()
+    np.testing.assert_allclose(got, np.linalg.solve((np.eye(R) + np.triu(U, 1)).T, (M - shift).T).T, rtol=1e-12, atol=1e-12)
+    assert int(flag.item()) == 0
+    Mn = M.copy()
+    Mn[I - 3, R - 1] = np.nan
+    be.unit_upper_solve_rows(_dev(Mn), _dev(U), _dev(shift), flag)
+    assert int(flag.item()) == 1
     LA, LB = rng.normal(size=(9, R)), rng.normal(size=(6, R))
     G = torch.empty(R * R, dtype=torch.float64, device="cuda:0")
     be.kr_gram(_dev(LA), G, True)
@@ -149,6 +159,54 @@ def test_projection_fixup_kernels(be):
     np.testing.assert_allclose(G.cpu().numpy().reshape(R, R), (LA.T @ LA) * (LB.T @ LB), rtol=1e-13)
     KR = (LA[:, None, :] * LB[None, :, :]).reshape(-1, R)
     np.testing.assert_array_equal(be.khatri_rao(_dev(LA), _dev(LB)).cpu().numpy(), KR)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("coupled", [False, True])
+def test_transform_reads_the_callers_tensor_once_and_in_place(dtype, coupled):
+    """transform / predict of NaN-free device tensors (tpls.py:122-186; cmtf.py:142-231): no copy of X, no centred
+    copy, X untouched -- the MTTKRP runs on the uncentred rows and the centring is applied to its I x R output.  The
+    means here are 50x the spread of the data, so a centring lost to cancellation would show at once."""
+    from cmtf_pls_amd import ctPLS, tPLS
+    td = getattr(torch, dtype)
+    x, y, _ = O.import_synthetic((3072, 128, 64), 6, 4, error=0.2, seed=12)
+    x = x + 50.0 * np.random.default_rng(1).normal(size=x.shape[1:])
+    xm = np.random.default_rng(2).normal(size=(3072, 40)) + 30.0
+    if dtype == "float32":
+        x, xm = x.astype(np.float32).astype(np.float64), xm.astype(np.float32).astype(np.float64)
+    if coupled:
+        m = ctPLS(3, dtype=dtype)
+        m.fit([x, xm], y)
+        fit = O.fit_ctpls([x, xm], y, 3)
+    else:
+        m = tPLS(3, dtype=dtype)
+        m.fit(x, y)
+        fit = O.fit_tpls(x, y, 3)
+    new = [x[:2048], xm[:2048]] if coupled else [x[:2048]]
+    dev = [torch.from_numpy(a).to(td).to("cuda:0") for a in new]
+    keep = [d.clone() for d in dev]
+    want = O.transform(fit, new)
+    arg = dev if coupled else dev[0]
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    got = m.transform(arg)
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < dev[0].numel() * dev[0].element_size() // 4, f"transform allocated {peak} bytes for a {dev[0].numel() * dev[0].element_size()}-byte X"
+    assert all(torch.equal(d, k) for d, k in zip(dev, keep))                       # inputs are never modified
+    rtol = 1e-5 if dtype == "float32" else 1e-9
+    scale = np.abs(want).max(axis=0)
+    assert (np.abs(got - want) / scale).max() < rtol
+    np.testing.assert_allclose(m.predict(arg), O.predict(fit, new), rtol=0, atol=rtol * 10 * np.abs(y).max())
+    # one missing value: the output flags it and the masked sequential path answers, on a private copy
+    dev[0][5, 7, 9] = float("nan")
+    new[0] = new[0].copy()
+    new[0][5, 7, 9] = np.nan
+    keep = [d.clone() for d in dev]
+    got = m.transform(arg)
+    want = O.transform(fit, new)
+    assert (np.abs(got - want) / scale).max() < rtol
+    assert all(torch.equal(torch.nan_to_num(d), torch.nan_to_num(k)) and torch.equal(torch.isnan(d), torch.isnan(k)) for d, k in zip(dev, keep))
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

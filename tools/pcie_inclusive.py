@@ -32,9 +32,11 @@ t, _ = clock(lambda: m.transform(xh64)); print(f"transform host f64 input: {t:.4
 t, _ = clock(lambda: m.predict(X)); print(f"predict device input: {t:.4f} s")
 m.transform(X, yh)
 t, _ = clock(lambda: m.transform(X, yh)); print(f"transform(X, Y) device X, host Y (Y side through rowdot / y_deflate): {t:.4f} s")
-# where transform's time goes (device input)
+# where transform's time goes (device input): the read-only one-pass form against the copy + centre + MTTKRP it replaced
 from cmtf_pls_amd.tpls import to_device_copy
 eng = m._get_engine()
-t, Xd = clock(lambda: to_device_copy(X, torch.float32, eng.be.device)); print(f"  device clone of X: {t:.4f} s")
-t, sc = clock(lambda: eng.project(m._state, [Xd])); print(f"  engine.project (centre + MTTKRP + fix-up): {t:.4f} s")
+t, sc = clock(lambda: eng.project_readonly(m._state, [X])); print(f"  engine.project_readonly (MTTKRP on the caller's X + shift + fix-up): {t:.4f} s")
+t, Xd = clock(lambda: to_device_copy(X, torch.float32, eng.be.device)); print(f"  [old path] device clone of X: {t:.4f} s")
+t, sc2 = clock(lambda: eng.project(m._state, [Xd])); print(f"  [old path] engine.project (centre + MTTKRP + fix-up): {t:.4f} s")
+print(f"  max |readonly - old| / max|scores| = {float((sc - sc2).abs().max() / sc2.abs().max()):.2e}")
 t, _ = clock(lambda: sc.cpu().numpy()); print(f"  scores to host: {t:.4f} s")
