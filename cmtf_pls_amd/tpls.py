@@ -148,20 +148,21 @@ class _EstimatorBase(Mapping):
         """Y-side epilogue of transform (tpls.py:167-184, cmtf.py:212-229): per component Y_scores[:, a] = Y q_a, then
         Y -= (X_scores coef_[:, a]) q_a^T.  Runs through the backend's rowdot / y_deflate kernels on the device-resident
         scores (the host form spends its time starting BLAS threads for I' x 16 products)."""
-        Y = Y.detach().cpu().numpy() if isinstance(Y, torch.Tensor) else np.asarray(Y)
+        Y = Y if isinstance(Y, torch.Tensor) else np.asarray(Y)
         if (Y.ndim != 1) and (Y.ndim != 2):
             raise ValueError("Only a matrix (2-mode tensor) Y is allowed.")
         if Y.ndim == 1:
             Y = Y.reshape((-1, 1))
-        if self.Y_shape[1:] != Y.shape[1:]:
-            raise ValueError(f"Training Y has shape {self.Y_shape}, while the new Y has shape {Y.shape}")
+        if self.Y_shape[1:] != tuple(Y.shape[1:]):
+            raise ValueError(f"Training Y has shape {self.Y_shape}, while the new Y has shape {tuple(Y.shape)}")
         eng = self._get_engine()
         be = eng.be
         R = self.n_components
         with eng.device_ctx():
             dev = X_scores.device if isinstance(X_scores, torch.Tensor) else be.device
             Xs = X_scores if isinstance(X_scores, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X_scores)).to(dev)
-            Yd = torch.from_numpy(np.array(Y, dtype=np.float64, copy=True) - self.Y_mean).to(dev)       # I' x M: small next to X
+            Yd = to_device_copy(Y, torch.float64, dev)                                                  # private copy: deflated below
+            be.center(Yd, torch.from_numpy(np.ascontiguousarray(self.Y_mean, dtype=np.float64)).to(dev), False)   # Y - Y_mean (tpls.py:178)
             Q = torch.from_numpy(np.ascontiguousarray(self.Y_factors[1].T)).to(dev)                     # row a = q_a
             C = torch.from_numpy(np.ascontiguousarray(self.coef_.T)).to(dev)                            # row a = coef_[:, a]
             Y_scores = be.zeros(Yd.shape[0], R)
