@@ -178,6 +178,12 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_s_downdate_f64(_ptr(S), S.shape[0], A, B, _ptr(ya), _ptr(wA), _ptr(wB), _ptr(q), _ptr(v),
                                                    self._stream()), "s_downdate")
 
+    def kr_axpy(self, v: torch.Tensor, A: int, B: int, WA: torch.Tensor, WB: torch.Tensor, k: int, coef: torch.Tensor) -> torch.Tensor:
+        """v (A*B) -= sum_{j<k} coef[j] * kron(WA[:, j], WB[:, j]); WA (A, R), WB (B, R) row-major."""
+        assert WA.is_contiguous() and WB.is_contiguous() and WA.shape[1] == WB.shape[1] and coef.numel() >= k
+        _lib.check(self.lib.cmtfpls_kr_axpy_f64(_ptr(v), A, B, _ptr(WA), _ptr(WB), WA.shape[1], int(k), _ptr(coef), self._stream()), "kr_axpy")
+        return v
+
     def quadform(self, G: torch.Tensor, q: torch.Tensor, q_old: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.check(self.lib.cmtfpls_quadform_f64(_ptr(G), G.shape[0], _ptr(q), _ptr(q_old), _ptr(out), self._stream()), "quadform")
         return out

@@ -238,6 +238,23 @@ __global__ __launch_bounds__(256) void s_downdate_kernel(double* __restrict__ S,
   }
 }
 
+// v[c] -= sum_{j < k} coef[j] * WA[(c / B) * ld + j] * WB[(c % B) * ld + j]: a rank-k correction in Khatri-Rao form, the
+// Khatri-Rao product never materialised.  Used by the xcov algorithm when X is NOT deflated in place: with
+// X_a = X_0 - sum_{j<a} t_j w_j^T the contraction the S down-date needs is X_{a+1}^T yhat = X_0^T yhat - sum_{j<=a} w_j (t_j^T yhat).
+__global__ __launch_bounds__(256) void kr_axpy_kernel(double* __restrict__ v, int64_t P, int B, const double* __restrict__ WA,
+                                                     const double* __restrict__ WB, int ld, int k, const double* __restrict__ coef) {
+  __shared__ double cs[64];
+  for (int j = threadIdx.x; j < k; j += 256) cs[j] = coef[j];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= P) return;
+  const double* __restrict__ wa = WA + (c / B) * ld;
+  const double* __restrict__ wb = WB + (c % B) * ld;
+  double s = 0.0;
+  for (int j = 0; j < k; ++j) s = fma(cs[j] * wa[j], wb[j], s);
+  v[c] -= s;
+}
+
 __global__ __launch_bounds__(256) void colscale_kernel(double* __restrict__ Z, int64_t P, const double* __restrict__ cnt, double n_samples) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c < P) Z[c] = (cnt[c] > 0.0) ? Z[c] / cnt[c] * n_samples : 0.0;
@@ -338,6 +355,15 @@ int cmtfpls_s_downdate_f64(double* S, int M, int A, int B, const double* ya, con
   const int64_t P = (int64_t)A * B;
   hipLaunchKernelGGL(s_downdate_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, M, P, B, ya, wA, wB, q, v);
   return check_launch("s_downdate");
+}
+
+int cmtfpls_kr_axpy_f64(double* v, int A, int B, const double* WA, const double* WB, int ld, int k, const double* coef, void* stream) {
+  if (!v || !WA || !WB || !coef || A <= 0 || B <= 0 || k < 0 || ld < k) { set_error("kr_axpy: bad argument"); return CMTFPLS_EINVAL; }
+  if (k > 64) { set_error("kr_axpy: more than 64 terms"); return CMTFPLS_EUNSUPPORTED; }
+  if (k == 0) return CMTFPLS_OK;
+  const int64_t P = (int64_t)A * B;
+  hipLaunchKernelGGL(kr_axpy_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, P, B, WA, WB, ld, k, coef);
+  return check_launch("kr_axpy");
 }
 
 // One inner iteration of the cross-covariance form issued by ONE host call (its kernels are tiny: a

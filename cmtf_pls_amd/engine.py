@@ -103,6 +103,10 @@ class FitState:
 
 
 class NipalsEngine:
+    # algorithm="xcov" on blocks without missing values: never deflate X in place (two reads per component instead of a
+    # read and a read + write, see FitRun._finish_xcov_nowrite); False keeps the deflating form (tests compare the two)
+    xcov_nowrite = True
+
     def __init__(self, backend, comm=None):
         self.be = backend
         self.comm = comm if comm is not None else _NoComm()
@@ -446,11 +450,19 @@ class FitRun:
             self._s_carry = (not any(blk.has_miss for blk in self.blocks)
                              and all(hasattr(be, f) for f in ("s_downdate", "deflate_contract_yq")))
             self._s_ready = False
+            self._nowrite = False
             if self._s_carry:
                 self.yhat = be.empty(I, 1)
                 self.one = be.empty(1)
                 self.one.fill_(1.0)
                 self.vs = [be.empty(blk.A * blk.B) for blk in self.blocks]
+                self._nowrite = bool(getattr(eng, "xcov_nowrite", False)) and hasattr(be, "kr_axpy") and R <= 64
+                if self._nowrite:
+                    # per component [t^T t, t^T t_b per block] (this rank's rows): |X_{b,a+1}|^2 = |X_{b,a}|^2 - 2 t^T t_b + t^T t
+                    # is evaluated on the host in result(), from the all-reduced dot products, instead of measured
+                    self.dot_log = be.zeros(R, 1 + len(self.blocks))
+                    self.Gw = be.empty(R * R)
+                    self._G_last = None
 
     def start_component(self, a: int) -> None:
         self._executed = 0
@@ -732,7 +744,10 @@ class FitRun:
         self.n_iter.append(self._executed)
         ssqs = []
         if self.algorithm == "xcov" and self._s_carry:
-            self._finish_xcov_carry(a)
+            if self._nowrite:
+                self._finish_xcov_nowrite(a)
+            else:
+                self._finish_xcov_carry(a)
             return
         if self.algorithm == "xcov":
             # the final score (tpls.py:92-99 with the converged loadings) and the deflation (tpls.py:109)
@@ -800,6 +815,7 @@ class FitRun:
             extra = packed[k * k + k:] if extra is not None else None
         b_dev = be.normal_solve(G, g.reshape(-1), out=self.b_dev[:k])
         self.coef_dev[:k, a].copy_(b_dev)
+        self._G_last = G                                     # T^T T (global): t_j^T (T b) = (G b)_j without another reduction
         return b_dev, extra
 
     def _finish_fused(self, a: int) -> None:
@@ -842,6 +858,9 @@ class FitRun:
         self.T[:, a].copy_(self.t)
         self.U[:, a].copy_(self.u)
         self.Q[:, a].copy_(self.q)
+        self._store_loadings(a)
+
+    def _store_loadings(self, a: int) -> None:
         for b, blk in enumerate(self.blocks):
             if len(blk.shape) == 2:
                 blk.loadings[0][:, a].copy_(self.wB[b])
@@ -892,17 +911,83 @@ class FitRun:
                 ssqs.append(be.deflate(self.X2[b], blk.A, blk.B, self.t, self.wA[b], self.wB[b]))   # tpls.py:109
         self._log_ssq(a, ssqs, ssqy)
 
+    def _finish_xcov_nowrite(self, a: int) -> None:
+        """finish_component of the xcov algorithm WITHOUT writing X (blocks without missing values).
+
+        The deflation X_{a+1} = X_a - t_a w_a^T (tpls.py:109) is linear, so X_a = X_0 - sum_{j<a} t_j w_j^T and nothing the
+        loop needs from X_a requires X_a itself:
+          score      X_a w_a = X_0 w_a - sum_{j<a} t_j (w_j^T w_a),   w_j^T w_a = prod_modes (W_m^T W_m)[j, a]            [one read]
+          down-date  X_{a+1}^T yhat = X_0^T yhat - sum_{j<=a} w_j (t_j^T yhat),   t_j^T yhat = (T^T T b)_j               [one read]
+          R2X        |X_{b,a+1}|^2 = |X_{b,a}|^2 - 2 t^T t_b + t^T t   (t_b: the block's own score; |w_b| = 1)   [result()]
+        Two reads of X per component instead of a read and a read + write; the last component needs no second pass
+        at all.  X stays as centred.  Same S, same iterations, same scores up to f64 rounding (tests compare this form with
+        the deflating one, `NipalsEngine.xcov_nowrite = False`)."""
+        be, comm = self.eng.be, self.eng.comm
+        self.q = self.qc
+        I, R, k = self.I, self.R, a + 1
+        nb = len(self.blocks)
+        self._store_loadings(a)
+        for b, blk in enumerate(self.blocks):
+            be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Ts[b])       # X_0 w_a
+            if a > 0:
+                for m, L in enumerate(blk.loadings):                             # Gram of a Khatri-Rao product =
+                    be.kr_gram(L, self.Gw, first=(m == 0))                       # Hadamard product of the mode Grams
+                g = self.Gw.view(R, R)[a, :a]                                    # w_j^T w_a, j < a (row a of the symmetric Gram)
+                be.y_deflate(self.Ts[b].view(I, 1), self.T, a, g, self.one)      # t_b -= T[:, :a] g
+        single = self.t.data_ptr() == self.Ts.data_ptr()
+        if not single:
+            be.scores_mean(self.Ts, self.t)                                      # cmtf.py:120
+        be.rowdot(self.Y, self.q, self.u, None)                                  # u = Y q (tpls.py:102)
+        be.gram_tn(self.t, self.t, out=self.dot_log[a, 0:1])
+        for b in range(nb):
+            if single:
+                self.dot_log[a, 1 + b].copy_(self.dot_log[a, 0])
+            else:
+                be.gram_tn(self.Ts[b], self.t, out=self.dot_log[a, 1 + b: 2 + b])
+        self.T[:, a].copy_(self.t)
+        self.U[:, a].copy_(self.u)
+        self.Q[:, a].copy_(self.q)
+        Ta = self.T[:, :k]
+        ya = be.gram_tn(self.Y, self.t).reshape(-1)                              # Y^T t with the not yet deflated Y
+        b_dev, ya_g = self._inner_regression(a, extra=ya)                        # tpls.py:110-112; ya_g: all-reduced Y^T t
+        if k < R:
+            be.rowdot(Ta, b_dev, self.yhat.view(-1), None)                       # yhat = T b (what Y is deflated by)
+        ssqy = be.y_deflate(self.Y, self.T, k, b_dev, self.q)                    # tpls.py:113
+        if k < R:
+            c = be.gram_tn(self._G_last, b_dev).reshape(-1)                      # t_j^T yhat = (T^T T b)_j, j <= a (global)
+            for b, blk in enumerate(self.blocks):
+                WA, WB = self.eng._kr_operands(blk, R)                           # columns <= a: the components so far
+                be.mode0_contract(self.X2[b], self.yhat.view(-1), False, out=self.vs[b])       # X_0^T yhat
+                comm.allreduce(self.vs[b])
+                be.kr_axpy(self.vs[b], blk.A, blk.B, WA, WB, k, c)
+                be.s_downdate(self.S[b], blk.A, blk.B, ya_g, self.wA[b], self.wB[b], self.q, self.vs[b])
+            self._s_ready = True
+        self.ssq_log[a, nb].copy_(ssqy.reshape(()))                              # tpls.py:118-120
+
     def result(self) -> FitState:
         """The only device -> host traffic of the component epilogues: the R x R coefficients and the
         R x (blocks + 1) deflated norms, all-reduced once, in one copy."""
         if getattr(self, "_state", None) is not None:             # the norms are all-reduced exactly once
             return self._state
         nb = len(self.blocks)
+        nowrite = self.algorithm == "xcov" and getattr(self, "_nowrite", False)
         self.eng.comm.allreduce(self.ssq_log)
-        host = torch.cat([self.coef_dev.reshape(-1), self.ssq_log.reshape(-1)]).cpu().numpy()
+        parts = [self.coef_dev.reshape(-1), self.ssq_log.reshape(-1)]
+        if nowrite:
+            self.eng.comm.allreduce(self.dot_log)
+            parts.append(self.dot_log.reshape(-1))
+        host = torch.cat(parts).cpu().numpy()
         R = self.R
         self.coef[...] = host[: R * R].reshape(R, R)
-        ssq = host[R * R:].reshape(R, nb + 1)
+        ssq = host[R * R: R * R + R * (nb + 1)].reshape(R, nb + 1).copy()
+        if nowrite:
+            # X was never deflated: |X_{b,a+1}|^2 = |X_{b,a}|^2 - 2 t_a^T t_{b,a} + t_a^T t_a from the logged dot products
+            dots = host[R * R + R * (nb + 1):].reshape(R, 1 + nb)
+            for b, blk in enumerate(self.blocks):
+                run = blk.ssq0
+                for a in range(len(self.n_iter)):
+                    run = run - 2.0 * dots[a, 1 + b] + dots[a, 0]
+                    ssq[a, b] = run
         for a in range(len(self.n_iter)):
             for b, blk in enumerate(self.blocks):
                 blk.r2x[a] = 1.0 - ssq[a, b] / blk.ssq0                          # tpls.py:115-117

@@ -129,6 +129,13 @@ int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double*
  * cmtfpls_deflate_contract_yq_* with Y = yhat as an I x 1 matrix and q = [1]),  w[c] = wA[c/B] wB[c%B]. */
 int cmtfpls_s_downdate_f64(double* S, int M, int A, int B, const double* ya, const double* wA, const double* wB,
                            const double* q, const double* v, void* stream);
+/* v[c] -= sum_{j<k} coef[j] WA[(c/B)*ld + j] WB[(c%B)*ld + j]  (k <= 64; WA: A x ld, WB: B x ld row-major): the xcov loop without
+ * writing X.  With X_a = X_0 - sum_{j<a} t_j w_j^T (tpls.py:109 unrolled) the deflated tensor is never formed:
+ *   final score   t_a = X_0 w_a - sum_{j<a} t_j (w_j^T w_a)            (cmtfpls_score_* on X_0, then cmtfpls_y_deflate_f64 on t),
+ *   down-date     v = X_{a+1}^T yhat = X_0^T yhat - sum_{j<=a} w_j (t_j^T yhat)   (cmtfpls_mode0_contract_* on X_0, then this entry),
+ *   R2X           |X_{a+1}|^2 = |X_a|^2 - 2 t^T t_b + t^T t  (t_b: the block's own score, = t for one block):
+ * two reads of X per component instead of a read and a read + write, and X_0 stays as centred. */
+int cmtfpls_kr_axpy_f64(double* v, int A, int B, const double* WA, const double* WB, int ld, int k, const double* coef, void* stream);
 /* Opt-in mixed-precision forms of xcov and mttkrp for f32-stored X: v_mfma_f32_16x16x4_f32 (half the
  * matrix cycles of the f64 form, HBM-bound instead of matrix-pipe-bound).  X is exact; the other
  * operand is rounded once to f32; f32 accumulation only inside chains of 64 rows (xcov) / 256 columns

@@ -97,6 +97,12 @@ class NumpyBackend:
         self.score(S, A, B, wA, wB, None, q_new)
         self.q_update(q_new, None, True, G, q_cur, du2)
 
+    def kr_axpy(self, v, A, B, WA, WB, k, coef):
+        W = (_np(WA)[:, None, :k] * _np(WB)[None, :, :k]).reshape(A * B, k)
+        vv = _np(v)
+        vv -= W @ _np(coef)[:k]
+        return v
+
     def s_downdate(self, S, A, B, ya, wA, wB, q, v):
         S -= torch.outer(ya.reshape(-1), torch.from_numpy(self._w(wA, wB))) + torch.outer(q, v)
 

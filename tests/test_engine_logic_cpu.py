@@ -195,6 +195,67 @@ def test_xcov_algorithm_equals_direct(case):
     np.testing.assert_allclose(b.R2Y, a.R2Y, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("case", ["tpls3", "tpls4", "matrix", "coupled", "more_components_than_rank"])
+def test_xcov_without_writing_x_equals_the_deflating_form(case, monkeypatch):
+    """algorithm="xcov" on NaN-free blocks never deflates X (FitRun._finish_xcov_nowrite): X_a = X_0 - sum t_j w_j^T is
+    carried implicitly.  Same scores, loadings, coefficients, R2X (from the norm recurrence) and iteration counts as the
+    form that deflates in place (NipalsEngine.xcov_nowrite = False) and as the direct loop; the engine's copy of X ends
+    the fit exactly as it was centred."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    rng = np.random.default_rng(77)
+    R = 4
+    if case == "coupled":
+        Xs = [rng.random((30, 6, 5, 4)), rng.random((30, 7, 3)), rng.random((30, 9))]
+    elif case == "tpls4":
+        Xs = [rng.random((30, 6, 5, 4))]
+    elif case == "matrix":
+        Xs = [rng.random((30, 24))]
+    elif case == "more_components_than_rank":
+        x, _, _ = O.import_synthetic((30, 7, 6), 3, 2, error=0.0, seed=3)       # X has CP rank 2, R = 4 asks for more
+        Xs = [x]
+    else:
+        Xs = [rng.random((30, 7, 6))]
+    Y = rng.random((30, 3))
+
+    def fit(nowrite, algorithm="xcov"):
+        monkeypatch.setattr(NipalsEngine, "xcov_nowrite", nowrite)
+        if len(Xs) > 1:
+            m = ctPLS(R, backend=NumpyBackend(), algorithm=algorithm)
+            m.fit(Xs, Y)
+            return m, m.factor_T, m.R2Xs, [f for fs in m.Xs_factors for f in fs[1:]]
+        m = tPLS(R, backend=NumpyBackend(), algorithm=algorithm)
+        m.fit(Xs[0], Y)
+        return m, m.X_factors[0], [m.R2X], m.X_factors[1:]
+
+    a, Ta, r2a, La = fit(False)
+    b, Tb, r2b, Lb = fit(True)
+    d, Td, r2d, Ld = fit(True, "direct")
+    tight = case != "more_components_than_rank"        # beyond the rank of X the extra components are rounding noise
+    ncmp = R if tight else 2
+    assert a.n_iter_[:ncmp] == b.n_iter_[:ncmp] == d.n_iter_[:ncmp]
+    for T_, r2_, L_, m_ in ((Ta, r2a, La, a), (Td, r2d, Ld, d)):
+        np.testing.assert_allclose(Tb[:, :ncmp], T_[:, :ncmp], rtol=1e-9, atol=1e-9)
+        for x1, x2 in zip(Lb, L_):
+            np.testing.assert_allclose(x1[:, :ncmp], x2[:, :ncmp], rtol=1e-8, atol=1e-9)
+        for x1, x2 in zip(r2b, r2_):                    # iterates agree to the convergence tolerance (1e-8), not to rounding
+            np.testing.assert_allclose(x1[:ncmp], x2[:ncmp], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(b.R2Y[:ncmp], m_.R2Y[:ncmp], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(b.coef_[:ncmp, :ncmp], m_.coef_[:ncmp, :ncmp], rtol=1e-7, atol=1e-9)
+    assert np.all(np.isfinite(b.coef_)) and np.all(np.isfinite(Tb))
+    if len(Xs) == 1:                                   # (a coupled fit's R2Xs need not increase: tests/test_cmtf.py:27,39)
+        assert np.all(np.diff(r2b[0]) >= -1e-9) and r2b[0][-1] <= 1 + 1e-9        # the norm recurrence stays monotone and <= 1
+    # the never-write fit leaves its working copy as centred
+    monkeypatch.setattr(NipalsEngine, "xcov_nowrite", True)
+    import torch
+    Xd = torch.from_numpy(Xs[0].copy())
+    m = (ctPLS if len(Xs) > 1 else tPLS)(R, backend=NumpyBackend(), algorithm="xcov", copy_X=False)
+    if len(Xs) > 1:
+        m.fit([Xd] + Xs[1:], Y)
+    else:
+        m.fit(Xd, Y)
+    np.testing.assert_allclose(Xd.numpy(), Xs[0] - Xs[0].mean(axis=0), rtol=0, atol=1e-13)
+
+
 @pytest.mark.parametrize("case", ["tpls3", "tpls4", "matrix", "coupled"])
 def test_one_pass_projection_equals_sequential(case):
     """transform/predict through one MTTKRP + R x R triangular solve == R project-and-deflate passes."""

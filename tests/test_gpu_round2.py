@@ -161,6 +161,67 @@ def test_projection_fixup_kernels(be):
     np.testing.assert_array_equal(be.khatri_rao(_dev(LA), _dev(LB)).cpu().numpy(), KR)
 
 
+def test_kr_axpy_kernel(be):
+    rng = np.random.default_rng(19)
+    for (A, B, R, k) in [(7, 9, 5, 3), (1, 300, 4, 4), (128, 128, 10, 10), (3, 5, 64, 64), (6, 4, 3, 0)]:
+        v, WA, WB, c = rng.normal(size=A * B), rng.normal(size=(A, R)), rng.normal(size=(B, R)), rng.normal(size=max(k, 1))
+        want = v - (WA[:, None, :k] * WB[None, :, :k]).reshape(A * B, k) @ c[:k]
+        got = be.kr_axpy(_dev(v), A, B, _dev(WA), _dev(WB), k, _dev(c)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("case", ["tpls", "coupled", "order4"])
+def test_xcov_without_writing_x_on_gpu(dtype, case, monkeypatch):
+    """algorithm="xcov" without deflating X (two reads per component, FitRun._finish_xcov_nowrite) against the form that
+    deflates in place and against the oracle; the device tensor handed over with copy_X=False ends the fit as centred."""
+    from cmtf_pls_amd import ctPLS, tPLS
+    from cmtf_pls_amd.engine import NipalsEngine
+    td = getattr(torch, dtype)
+    R = 4
+    if case == "order4":
+        x, y, _ = O.import_synthetic((600, 12, 8, 6), 5, R, error=0.2, seed=21)
+    else:
+        x, y, cp = O.import_synthetic((2048, 128, 64), 6, R, error=0.2, seed=21)
+    Xs = [x]
+    if case == "coupled":
+        Xs.append(cp.factors[0] @ np.random.default_rng(3).normal(size=(40, R)).T + 0.1 * np.random.default_rng(4).normal(size=(2048, 40)))
+    if dtype == "float32":
+        Xs = [a.astype(np.float32).astype(np.float64) for a in Xs]
+    fit = O.fit_ctpls(Xs, y, R) if case == "coupled" else O.fit_tpls(Xs[0], y, R)
+
+    def run(nowrite, keep=None):
+        monkeypatch.setattr(NipalsEngine, "xcov_nowrite", nowrite)
+        if case == "coupled":
+            m = ctPLS(R, dtype=dtype, algorithm="xcov", copy_X=keep is None)
+            m.fit(Xs if keep is None else keep, y)
+            return m, m.factor_T, m.R2Xs[0]
+        m = tPLS(R, dtype=dtype, algorithm="xcov", copy_X=keep is None)
+        m.fit(Xs[0] if keep is None else keep[0], y)
+        return m, m.X_factors[0], m.R2X
+
+    a, Ta, r2a = run(False)
+    b, Tb, r2b = run(True)
+    assert a.n_iter_ == b.n_iter_
+    scale = np.abs(fit.T).max(axis=0)
+    tight = 1e-9 if dtype == "float64" else 2e-6          # f32 storage: the deflating form rounds X to f32 once per component
+    assert (np.abs(Tb - Ta) / scale).max() < tight
+    np.testing.assert_allclose(r2b, r2a, rtol=0, atol=1e-8 if dtype == "float64" else 1e-6)
+    np.testing.assert_allclose(b.coef_, a.coef_, rtol=0, atol=(1e-8 if dtype == "float64" else 1e-5) * np.abs(a.coef_).max())
+    rtol = 1e-7 if dtype == "float64" else 1e-5
+    assert (np.abs(Tb - fit.T) / scale).max() < rtol
+    np.testing.assert_allclose(r2b, fit.r2x[0], rtol=0, atol=rtol)
+    np.testing.assert_allclose(b.R2Y, fit.r2y, rtol=0, atol=rtol)
+    assert list(b.n_iter_) == list(fit.n_iter) or dtype == "float32"
+    # copy_X=False: the caller's tensors are centred by the fit and then only read
+    dev = [torch.from_numpy(v).to(td).to("cuda:0") for v in Xs]
+    c, Tc, _ = run(True, keep=dev)
+    np.testing.assert_allclose(Tc, Tb, rtol=0, atol=0)
+    for d, v in zip(dev, Xs):
+        centred = v - v.mean(axis=0)
+        np.testing.assert_allclose(d.cpu().numpy().astype(np.float64), centred, rtol=0, atol=(1e-12 if dtype == "float64" else 1e-6) * np.abs(v).max())
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("coupled", [False, True])
 def test_transform_reads_the_callers_tensor_once_and_in_place(dtype, coupled):
