@@ -20,7 +20,9 @@ Rank 0 prints ONE JSON line; ``roofline`` is the dominant kernel (the mode-0 con
 events on the launch stream inside the timed region, against the 8 TB/s spec peak AND against streaming
 ceilings measured in the same run (``peak_measured_read`` / ``peak_measured_rmw``: plain float4
 read-only / read-modify-write kernels of libcmtfpls over an X-sized buffer); ``cpu_baseline`` is the
-NumPy oracle's inner loop timed on this host on a row sample (rank 0, N=1 only).
+NumPy oracle's inner loop timed on this host on a row sample (rank 0, N=1 only).  ``fit`` is the sec-to-fit leg: whole
+fits (default tol / max_iter, preprocessing included) through the direct loop, the cross-covariance form and its
+f32-MFMA variant, each run twice (``first_call_seconds``, ``seconds``).
 """
 import argparse
 import json
@@ -373,40 +375,39 @@ def main():
     fit_info = None
     mfma = None
     if not args.no_fit:
-        Xf, Yf = X.clone(), Y.clone()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        st = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False)
-        torch.cuda.synchronize()
-        fit_s = time.perf_counter() - t1
-        fit_info = {"seconds": fit_s, "n_iter": list(st.n_iter), "iters_per_sec_in_fit": sum(st.n_iter) / fit_s,
+        def timed_fit(**kw):
+            """One whole fit on a fresh copy of the resident X (the clone is outside the timed region; the fit's own
+            preprocessing -- column statistics, centring -- is inside).  Returns (state, seconds)."""
+            Xf, Yf = X.clone(), Y.clone()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            state = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, **kw)
+            torch.cuda.synchronize()
+            return state, time.perf_counter() - t1
+
+        # every fit is run twice: "first_call_seconds" includes what a process pays once (code objects of kernels not used
+        # by the timed steps above, workspaces growing to size), "seconds" is the second call
+        st, fit_first = timed_fit()
+        st, fit_s = timed_fit()
+        fit_info = {"seconds": fit_s, "first_call_seconds": fit_first, "n_iter": list(st.n_iter),
+                    "iters_per_sec_in_fit": sum(st.n_iter) / fit_s,
                     "R2X_final": float(st.blocks[0].r2x[-1]), "R2Y_final": float(st.r2y[-1]), "tol": 1e-8, "max_iter": 100}
-        del Xf, Yf
-        # the same fit through the cross-covariance form (algorithm="xcov": S = X^T Y on the f64 matrix
-        # cores, inner loop on S; exact re-association, one X read + one read/write per component)
-        Xf, Yf = X.clone(), Y.clone()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        sx = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov")
-        torch.cuda.synchronize()
-        xs = time.perf_counter() - t1
-        fit_info["xcov"] = {"seconds": xs, "n_iter": list(sx.n_iter), "iters_per_sec_in_fit": sum(sx.n_iter) / xs,
+        # the same fit through the cross-covariance form (algorithm="xcov": S = X^T Y on the f64 matrix cores for the
+        # first component and carried by down-dates afterwards, inner loop on S; exact re-association; X is read twice
+        # per component and, without missing values, never written after the centring)
+        sx, xs_first = timed_fit(algorithm="xcov")
+        sx, xs = timed_fit(algorithm="xcov")
+        fit_info["xcov"] = {"seconds": xs, "first_call_seconds": xs_first, "n_iter": list(sx.n_iter),
+                            "iters_per_sec_in_fit": sum(sx.n_iter) / xs,
                             "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
                             "max_abs_dT_vs_direct": float((sx.T - st.T).abs().max())}
-        del Xf, Yf
         # opt-in mixed precision of the S build (f32 MFMA, csrc/mixed.hip): reported, never the headline
-        Xf, Yf = X.clone(), Y.clone()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        sm = eng.fit([Xf], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov", mixed=True)
-        torch.cuda.synchronize()
-        fit_info["xcov_mixed_f32mfma"] = {"seconds": time.perf_counter() - t1, "n_iter": list(sm.n_iter),
+        sm, xm_first = timed_fit(algorithm="xcov", mixed=True)
+        sm, xm = timed_fit(algorithm="xcov", mixed=True)
+        fit_info["xcov_mixed_f32mfma"] = {"seconds": xm, "first_call_seconds": xm_first, "n_iter": list(sm.n_iter),
                                           "max_abs_dT_vs_direct": float((sm.T - st.T).abs().max())}
-        del Xf, Yf
         # the two matrix-core kernels, WARM (workspaces sized, 1 untimed + 5 timed launches each): achieved HBM rate
         # and matrix-pipe utilisation = flops / (time x 78.6 TF), the north star's "MFMA utilisation on the contraction"
         X2 = X.view(rows, -1)
