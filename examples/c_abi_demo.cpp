@@ -1,6 +1,7 @@
 // Torch-free use of libcmtfpls through its C ABI (include/cmtfpls.h): one NIPALS iteration and a
 // deflation on a small order-3 tensor, with plain hipMalloc buffers, checked against host loops.
 // Build: cmtf_pls_amd/csrc/build.sh (-> examples/c_abi_demo).   Run: examples/c_abi_demo   (exit 0 = ok)
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -30,6 +31,39 @@ static double maxdiff(const std::vector<double>& a, const std::vector<double>& b
   double m = 0;
   for (size_t i = 0; i < a.size(); ++i) m = fmax(m, fabs(a[i] - b[i]));
   return m;
+}
+
+// The collectives of the sharded loop without torch: a ONE-rank RCCL communicator (what one GPU can run), the Z of the
+// iteration above all-reduced in place through cmtfpls_allreduce_sum_f64.  RCCL is opened at run time (so this demo
+// links no RCCL either); with ranks on several GPUs the call is the same and sums the ranks' partial Z.
+// Returns 0 ok, 1 failed, -1 RCCL not usable here (reported, not an error of the C ABI).
+static int rccl_one_rank_allreduce(double* dZ, int64_t P, hipStream_t st) {
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { printf("rccl: library not found (%s)\n", dlerror()); return -1; }
+  struct UniqueId { char internal[128]; };                                     // rccl.h: NCCL_UNIQUE_ID_BYTES
+  typedef int (*get_id_fn)(UniqueId*);
+  typedef int (*init_fn)(void**, int, UniqueId, int);
+  typedef int (*destroy_fn)(void*);
+  get_id_fn get_id = (get_id_fn)dlsym(h, "ncclGetUniqueId");
+  init_fn init = (init_fn)dlsym(h, "ncclCommInitRank");
+  destroy_fn destroy = (destroy_fn)dlsym(h, "ncclCommDestroy");
+  if (!get_id || !init || !destroy) { printf("rccl: symbols missing\n"); return -1; }
+  UniqueId id;
+  void* comm = nullptr;
+  int rc = get_id(&id);
+  if (rc == 0) rc = init(&comm, 1, id, 0);
+  if (rc != 0 || !comm) { printf("rccl: one-rank communicator not available here (ncclResult %d)\n", rc); return -1; }
+  std::vector<double> before = to_host(dZ, (size_t)P);
+  const int arc = cmtfpls_allreduce_sum_f64(comm, dZ, (size_t)P, st);
+  if (arc != CMTFPLS_OK) { fprintf(stderr, "cmtfpls_allreduce_sum_f64 -> %d (%s)\n", arc, cmtfpls_last_error()); destroy(comm); return 1; }
+  if (hipStreamSynchronize(st) != hipSuccess) { destroy(comm); return 1; }
+  std::vector<double> after = to_host(dZ, (size_t)P);
+  destroy(comm);
+  for (int64_t p = 0; p < P; ++p)
+    if (after[p] != before[p]) { printf("rccl: one-rank all-reduce changed element %lld\n", (long long)p); return 1; }
+  printf("rccl: one-rank all-reduce(sum) of Z (%lld doubles) through cmtfpls_allreduce_sum_f64 OK\n", (long long)P);
+  return 0;
 }
 
 int main() {
@@ -119,6 +153,7 @@ int main() {
          cmtfpls_abi_version(), e_z, sigma, na, nb, res / fabs(sigma), e_t, e_q, e_x, fabs(ssq_d - ssq_h) / ssq_h);
   const bool ok = e_z < 1e-9 && fabs(na - 1) < 1e-12 && fabs(nb - 1) < 1e-12 && res / fabs(sigma) < 1e-9 && sigma > 0 &&
                   e_t < 1e-9 && e_q < 1e-10 && e_x < 1e-6 && fabs(ssq_d - ssq_h) / ssq_h < 1e-10;
-  printf(ok ? "C ABI demo OK\n" : "C ABI demo FAILED\n");
-  return ok ? 0 : 1;
+  const int coll = rccl_one_rank_allreduce(dZ, P, st);
+  printf((ok && coll != 1) ? "C ABI demo OK\n" : "C ABI demo FAILED\n");
+  return (ok && coll != 1) ? 0 : 1;
 }

@@ -234,6 +234,15 @@ int cmtfpls_y_deflate_f64(double* Y, int ldy, int M, int64_t I, const double* T,
                           void* stream);
 int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
 
+/* ---- collectives of the sharded loop for callers that drive this C ABI directly -----------------------
+ * In-place all-reduce(sum) of a device buffer over the caller's RCCL communicator (an ncclComm_t passed as void*), on
+ * `stream`: Z (P doubles) and Y^T t (M doubles) per direct iteration, T^T [T | u] per component, S per component with
+ * the cross-covariance form.  The library does not link RCCL: ncclAllReduce is resolved at first use from the RCCL
+ * already loaded in the process (the one the communicator came from), else from librccl.so.1 on the loader path;
+ * CMTFPLS_EUNSUPPORTED when there is none.  (The Python package issues the same collectives through its own process group.) */
+int cmtfpls_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream);
+int cmtfpls_allreduce_sum_f32(void* comm, float* buf, size_t count, void* stream);
+
 /* ---- K7 / K8 / projection fix-up without a host round trip ------------------------------------------
  * normal_solve: b (k entries, stride incb) = argmin |T b - u| from the k x k normal equations G b = g with
  *   G = T^T T, g = T^T u (row-major f64, k <= 64): `np.linalg.lstsq(T, u, rcond=-1)[0]` of tpls.py:110-112 /

@@ -15,6 +15,8 @@ def test_c_abi_demo_runs():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C ABI demo OK" in out.stdout
+    # the RCCL wrapper (cmtfpls_allreduce_sum_f64) on a one-rank communicator created without torch
+    assert "through cmtfpls_allreduce_sum_f64 OK" in out.stdout, out.stdout
 
 
 def test_python_quickstart_runs():
