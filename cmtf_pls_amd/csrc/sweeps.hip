@@ -88,7 +88,14 @@ __device__ __forceinline__ void rows_times_q(const double* __restrict__ Y, int l
 // YQ: u is not read; u[i] = Y[i, :] . q is formed per workgroup in LDS, kYqChunk rows at a time
 // FULL: every column group of every thread exists (P is a multiple of the column tile): no guards, so the 4 x U loads
 // of a trip are issued back to back (with guards each load sits in its own exec-masked block).
-template <typename T, int MODE, bool YQ, int U, bool FULL>
+// ILV (only with u read from memory): the row blocks are INTERLEAVED -- block rb takes rows rb, rb + RB, rb + 2 RB, ... --
+// so that all workgroups advance through the tensor together, inside a window of RB x RU consecutive rows (16 MB at
+// 256 x 256 f32) instead of RB fronts that lie I / RB rows (gigabytes) apart: on a 68.7 GB tensor the contiguous
+// row blocks lose 5-10 % (profiles/r02bf_contract_forms_cfg5.txt: 6.2-6.4 -> 6.85-6.99 TB/s at 262144 x 256 x 256 inside
+// bench.py, no difference at <= 131072 rows).  A read-only sibling of deflate_contract_rows_kernel (1024-thread workgroup
+// per 64 KB row segment, rows interleaved by construction) was measured next to it: 6.35-6.43 TB/s there and 6.65-6.75
+// at the smaller sizes, where this kernel reaches 7.0-7.2 -- not kept.
+template <typename T, int MODE, bool YQ, int U, bool FULL, bool ILV = false>
 __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     const T* __restrict__ X, int64_t I, int64_t P, const double* __restrict__ u,
     double* __restrict__ part, double* __restrict__ cntpart, int rows_per_block,
@@ -98,8 +105,10 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
   using VT = typename VecOf<T>::type;
   const TileId tile = xcd_tile();                       // the column tiles of a row block share one XCD's L2
   const int64_t cbase = (int64_t)tile.ct * (kSweepThreads * V * U) + (int64_t)threadIdx.x * V;
-  const int64_t r0 = (int64_t)tile.rb * rows_per_block;
-  const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  static_assert(!(ILV && YQ), "interleaved row blocks read u from memory");
+  const int64_t rs = ILV ? (int64_t)gridDim.y : 1;                           // row step (compile-time 1 without ILV)
+  const int64_t r0 = ILV ? (int64_t)tile.rb : (int64_t)tile.rb * rows_per_block;
+  const int64_t r1 = ILV ? I : ((r0 + rows_per_block < I) ? r0 + rows_per_block : I);
   double acc[U][V];
   double cnt[U][V];
   bool ok[U];
@@ -120,15 +129,15 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
     rows_times_q(Y, ldy, M, q, r0, r1, us);
   }
   int64_t r = r0;
-  for (; r + RU <= r1; r += RU) {
+  for (; r + (RU - 1) * rs < r1; r += RU * rs) {
     VT x[RU][U];
     double uu[RU];
 #pragma unroll
     for (int s = 0; s < RU; ++s) {
-      uu[s] = (MODE == 2) ? 1.0 : YQ ? us[r + s - r0] : u[r + s];
+      uu[s] = (MODE == 2) ? 1.0 : YQ ? us[r + s - r0] : u[r + s * rs];
 #pragma unroll
       for (int g = 0; g < U; ++g)
-        if (FULL || ok[g]) x[s][g] = ld_stream(reinterpret_cast<const VT*>(X + (r + s) * P + cbase + (int64_t)g * kSweepThreads * V));
+        if (FULL || ok[g]) x[s][g] = ld_stream(reinterpret_cast<const VT*>(X + (r + s * rs) * P + cbase + (int64_t)g * kSweepThreads * V));
     }
 #pragma unroll
     for (int s = 0; s < RU; ++s)
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(kSweepThreads) void contract_vec_kernel(
           }
         }
   }
-  for (; r < r1; ++r) {
+  for (; r < r1; r += rs) {
     const double ur = (MODE == 2) ? 1.0 : YQ ? us[r - r0] : u[r];
 #pragma unroll
     for (int g = 0; g < U; ++g)
@@ -571,8 +580,14 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   const ContractPlan p = wideU ? p4 : plan_contract(I, P, (int)sizeof(T), 2, full2 ? kContractBlocksFull : kContractBlocks);
   const bool fullt = wideU ? full4 : full2;
 #define CV_LAUNCH1(YQF, UU, FF, LDS, UPTR, YP, LDY, MM, QP)                                                                          \
-  hipLaunchKernelGGL((contract_vec_kernel<T, MODE, YQF, UU, FF>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR, part, cntpart,    \
-                     p.rows_per_block, YP, LDY, MM, QP)
+  do {                                                                                                                               \
+    if (!YQF && ilv)                                                                                                                 \
+      hipLaunchKernelGGL((contract_vec_kernel<T, MODE, false, UU, FF, true>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR,      \
+                         part, cntpart, p.rows_per_block, YP, LDY, MM, QP);                                                          \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((contract_vec_kernel<T, MODE, YQF, UU, FF, false>), grid, dim3(kSweepThreads), LDS, st, X, I, P, UPTR,       \
+                         part, cntpart, p.rows_per_block, YP, LDY, MM, QP);                                                          \
+  } while (0)
 #define CV_LAUNCH(YQF, LDS, UPTR, YP, LDY, MM, QP)                                                                                   \
   do {                                                                                                                               \
     if (wideU && fullt) CV_LAUNCH1(YQF, ((MODE == 2) ? 2 : 4), true, LDS, UPTR, YP, LDY, MM, QP);                                     \
@@ -584,6 +599,11 @@ static int run_contract(const T* X, int64_t I, int64_t P, const double* u, doubl
   // u = Y q prologue, so u is formed once by the rowdot kernel into the tail of the workspace instead
   // (262144 x 256 x 256, M = 32: 2 % of the sweep)
   const bool yq_pre = yq && p.vec && M <= 64 && MODE != 2 && p.col_tiles >= kYqUnfuseTiles;
+  // interleaved row blocks (see contract_vec_kernel) for wide rows whose u comes from memory
+#ifndef CMTFPLS_CONTRACT_ILV
+#define CMTFPLS_CONTRACT_ILV 1
+#endif
+  const bool ilv = MODE != 2 && p.vec && (CMTFPLS_CONTRACT_ILV == 2 || (CMTFPLS_CONTRACT_ILV == 1 && p.col_tiles >= kYqUnfuseTiles));
   const size_t need = (size_t)p.row_blocks * (size_t)P * sizeof(double) * (MODE == 2 ? 2 : 1) + (yq_pre ? (size_t)I * sizeof(double) : 0);
   if (!ws || ws_bytes < need) { set_error("mode0_contract/colstats: workspace too small"); return CMTFPLS_EWORKSPACE; }
   double* part = static_cast<double*>(ws);
