@@ -42,6 +42,8 @@ SIGNATURES = {
     "cmtfpls_quadform_f64": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "cmtfpls_xcov_iterate_f64": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_size_t, _P, c_size_t, _P]),
     "cmtfpls_s_downdate_f64": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "cmtfpls_project_rows_f32": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "cmtfpls_project_rows_f64": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "cmtfpls_allreduce_sum_f64": (c_int, [_P, _P, c_size_t, _P]),
     "cmtfpls_allreduce_sum_f32": (c_int, [_P, _P, c_size_t, _P]),
     "cmtfpls_kr_axpy_f64": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),

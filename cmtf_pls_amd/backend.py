@@ -317,6 +317,18 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_khatri_rao_f64(_ptr(Am), na, _ptr(Bm), nb, R, _ptr(out), self._stream()), "khatri_rao")
         return out
 
+    def project_rows(self, X2: torch.Tensor, A: int, B: int, WA: torch.Tensor, WB: torch.Tensor, mean: Optional[torch.Tensor],
+                     out: torch.Tensor) -> Optional[torch.Tensor]:
+        """out (I, R) = the R sequential masked project-and-deflate steps of every row of the UNCENTRED X2, the row kept in
+        registers (one read, nothing written); None when the shape is outside that form."""
+        I, R = X2.shape[0], WA.shape[1]
+        assert WA.is_contiguous() and WB.is_contiguous() and out.stride(1) == 1 and out.shape == (I, R)
+        rc = self._fn("project_rows", X2)(_ptr(X2), I, A, B, R, _ptr(WA), _ptr(WB), _ptr(mean), _ptr(out), out.stride(0), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "project_rows")
+        return out
+
     def predict_rows(self, S: torch.Tensor, Bm: torch.Tensor, mean: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         """out (I, M) = S (I, R) @ Bm (R, M) + mean: the last line of predict (tpls.py:143) on the device-resident scores."""
         I, R = S.shape

@@ -210,15 +210,25 @@ class NipalsEngine:
         the UNCENTRED rows and the centring `X - X_mean` (tpls.py:130,153; cmtf.py:150,187) is applied to its I x R output,
         (X - 1 mean^T) W = X W - 1 (mean^T W)^T.  None when this form does not apply -- a missing value anywhere in Xs
         (seen as a NaN in the MTTKRP output), a training column without observations (NaN mean), a shape the MTTKRP does
-        not take -- and the caller then runs `project` on private copies."""
+        not take and that has no row-in-registers form either -- and the caller then runs `project` on private copies."""
         with self.device_ctx():
             if any(bool(torch.isnan(blk.mean).any().item()) for blk in state.blocks):
                 return None
             flag = torch.zeros(1, dtype=torch.int32, device=self.be.device)
             scores = self._project_one_pass(state, Xs, False, centred=False, nan_flag=flag)
-            if scores is None or int(flag.item()) != 0:
-                return None
-            return scores
+            if scores is not None and int(flag.item()) == 0:
+                return scores
+            # a missing value somewhere: the reference's masked sequence -- centre, then R times score with the per-row
+            # rescale and deflate (tpls.py:128-142, missingvals.py:23-38) -- run on every row in registers, from one read
+            # of the uncentred block (one block; coupled blocks share their score per step and keep the passes)
+            be = self.be
+            if scores is not None and len(state.blocks) == 1 and hasattr(be, "project_rows"):
+                blk, I, R = state.blocks[0], Xs[0].shape[0], state.n_components
+                WA, WB = self._kr_operands(blk, R)
+                out = be.empty(I, R)
+                if be.project_rows(Xs[0].view(I, -1), blk.A, blk.B, WA, WB, blk.mean, out) is not None:
+                    return out
+            return None
 
     def _project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool, mixed: bool) -> torch.Tensor:
         be = self.be

@@ -234,6 +234,18 @@ int cmtfpls_y_deflate_f64(double* Y, int ldy, int M, int64_t I, const double* T,
                           void* stream);
 int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
 
+/* project_rows: transform / predict of samples WITH missing values (tpls.py:128-142 with miss_mmodedot, missingvals.py:23-38) from
+ * ONE read of the uncentred X, nothing written: a workgroup keeps one row in registers and runs the reference's whole sequence
+ * on it -- x - mean (rounded to the storage type, as the centred copy would be), the observation count, and for a = 0..R-1 the
+ * masked score t_a = (sum_obs x w_a) * P / n_obs, scores[i*ld + a] = t_a, x -= t_a w_a (rounded to the storage type) --
+ * instead of a centring pass and R read + write passes (cmtfpls_score_deflate_*).  WA (A x R), WB (B x R) row-major, mean (P,
+ * nullable = 0).  CMTFPLS_EUNSUPPORTED for rows longer than 4096 16-byte vectors, a trailing extent B that does not divide
+ * 256 * (16 / sizeof(T)) elements, or R (A + B) doubles beyond 64 KB of LDS: the caller keeps the passes. */
+int cmtfpls_project_rows_f32(const float* X, int64_t I, int A, int B, int R, const double* WA, const double* WB,
+                             const double* mean, double* scores, int ld, void* stream);
+int cmtfpls_project_rows_f64(const double* X, int64_t I, int A, int B, int R, const double* WA, const double* WB,
+                             const double* mean, double* scores, int ld, void* stream);
+
 /* ---- collectives of the sharded loop for callers that drive this C ABI directly -----------------------
  * In-place all-reduce(sum) of a device buffer over the caller's RCCL communicator (an ncclComm_t passed as void*), on
  * `stream`: Z (P doubles) and Y^T t (M doubles) per direct iteration, T^T [T | u] per component, S per component with

@@ -452,3 +452,50 @@ def test_random_problems_match_oracle_on_gpu(seed):
     np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(tr, want_tr, rtol=1e-6, atol=1e-8 * s)
     np.testing.assert_allclose(rec, O.reconstruct(fit, 0), rtol=1e-6, atol=1e-7 * max(1.0, np.nanmax(np.abs(X))))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("shape,R", [((700, 128, 128), 10), ((300, 24, 32), 5), ((257, 1, 512), 3), ((64, 100, 8), 7), ((90, 6, 256), 2)])
+def test_project_rows_kernel_matches_the_sequential_passes(be, shape, R, dtype):
+    """cmtfpls_project_rows_*: centring + R masked project-and-deflate steps with the row in registers (one read of the raw
+    X) against the passes it replaces (centre, then R x score_deflate), on rows with and without missing values, an
+    empty row included: same scores to rounding (same per-element arithmetic and summation order), X untouched."""
+    rng = np.random.default_rng(5)
+    I, A, B = shape
+    td = getattr(torch, dtype)
+    x = rng.normal(size=(I, A * B)) + 3.0
+    x[rng.random(x.shape) < 0.2] = np.nan
+    x[::7] = np.nan_to_num(x[::7], nan=0.5)          # complete rows too
+    x[5] = np.nan                                    # an empty row -> NaN scores
+    if dtype == "float32":
+        x = x.astype(np.float32).astype(np.float64)
+    mean = np.nanmean(x, axis=0) + 0.01
+    WA, WB = rng.normal(size=(A, R)), rng.normal(size=(B, R))
+    WA /= np.linalg.norm(WA, axis=0); WB /= np.linalg.norm(WB, axis=0)
+    Xd = _dev(x).to(td)
+    keep = Xd.clone()
+    got = be.project_rows(Xd, A, B, _dev(WA), _dev(WB), _dev(mean), be.empty(I, R))
+    V = 16 // Xd.element_size()
+    if A * B > 4096 * V or (256 * V) % B != 0:           # a row beyond 4096 16-byte vectors, or B not dividing the stride: declined
+        assert got is None
+        return
+    assert got is not None
+    assert torch.equal(torch.nan_to_num(Xd), torch.nan_to_num(keep)) and torch.equal(torch.isnan(Xd), torch.isnan(keep))
+    # the sequential passes on a copy
+    Xc = keep.clone()
+    rowcnt, _ = be.center(Xc, _dev(mean), True)
+    want = be.empty(I, R)
+    t = be.empty(I)
+    for a in range(R):
+        wa, wb = _dev(WA[:, a].copy()), _dev(WB[:, a].copy())
+        if be.score_deflate(Xc, A, B, wa, wb, rowcnt, t) is None:
+            be.score(Xc, A, B, wa, wb, rowcnt, t)
+            be.deflate(Xc, A, B, t, wa, wb)
+        want[:, a].copy_(t)
+    g, w = got.cpu().numpy(), want.cpu().numpy()
+    assert np.array_equal(np.isnan(g), np.isnan(w)) and np.isnan(g[5]).all()
+    ok = ~np.isnan(w)
+    scale = np.abs(w[ok]).max()
+    assert np.abs(g[ok] - w[ok]).max() <= (1e-12 if dtype == "float64" else 1e-6) * scale
+    # shapes outside the form are declined, not mangled
+    assert be.project_rows(_dev(np.zeros((4, 3 * 5))).to(td), 3, 5, _dev(np.ones((3, 2))), _dev(np.ones((5, 2))), None, be.empty(4, 2)) is None
