@@ -53,9 +53,11 @@ __global__ __launch_bounds__(kProjThreads) void project_rows_kernel(const T* __r
 #pragma unroll
     for (int n = 0; n < NV; ++n)
       if (c0 + n * stride < P) {
+        unsigned cm = c0 + n * stride;
+        asm volatile("" : "+v"(cm));                                  // one offset at a time, not NV of them kept per lane
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const double mu = mean ? mean[c0 + n * stride + e] : 0.0;   // L2-resident; a register copy would cost 2 * NV * V VGPRs
+          const double mu = mean ? mean[cm + e] : 0.0;                // L2-resident; a register copy would cost 2 * NV * V VGPRs
           const T nv = (T)((double)x[n].e[e] - mu);                   // the centred copy, in the storage type (NaN stays NaN)
           x[n].e[e] = nv;
           cnt += (nv == nv) ? 1.0 : 0.0;
@@ -90,7 +92,9 @@ __global__ __launch_bounds__(kProjThreads) void project_rows_kernel(const T* __r
             const T xv = x[n].e[e];
             d = fma((xv == xv) ? (double)xv : 0.0, wb[e], d);
           }
-          acc = fma(sAa[j0 + n * dj], d, acc);
+          int jn = j0 + n * dj;
+          asm volatile("" : "+v"(jn));                             // no per-vector LDS address kept (and advanced) across the loops
+          acc = fma(sAa[jn], d, acc);
           if (NV > 4) __builtin_amdgcn_sched_barrier(0);          // keep live temporaries low: the row owns the VGPRs
         }
       acc = wave_sum(acc);
@@ -109,7 +113,9 @@ __global__ __launch_bounds__(kProjThreads) void project_rows_kernel(const T* __r
 #pragma unroll
       for (int n = 0; n < NV; ++n)
         if (c0 + n * stride < P) {
-          const double tw = ti * sAa[j0 + n * dj];
+          int jn = j0 + n * dj;
+          asm volatile("" : "+v"(jn));
+          const double tw = ti * sAa[jn];
 #pragma unroll
           for (int e = 0; e < V; ++e) x[n].e[e] = (T)fma(-tw, wb[e], (double)x[n].e[e]);   // tpls.py:142 on the stored type
           if (NV > 4) __builtin_amdgcn_sched_barrier(0);
