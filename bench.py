@@ -56,6 +56,9 @@ def parse(argv=None):
     ap.add_argument("--no-ceilings", action="store_true", help="skip the measured streaming ceilings")
     ap.add_argument("--cpu-rows", type=int, default=2048)
     ap.add_argument("--graphs", type=int, default=1, help="replay the iteration's launch sequence as a HIP graph (0 = eager)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed windows of exactly --steps iterations each; value = median")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 262144x256x256 leg (BASELINE.json north_star)")
+    ap.add_argument("--north-star-steps", type=int, default=10)
     return ap.parse_args(argv)
 
 
@@ -154,6 +157,116 @@ def cpu_baseline(J, K, M, L, noise, rows, I_total):
             "sample": f"oracle.nipals_inner_loop (NumPy f64) on {rows} of {I_total} rows x {J}x{K}, {n} iterations in "
                       f"{dt:.1f} s = {per_iter_sample*1e3:.1f} ms/iter on the sample, scaled linearly in rows",
             "host_cpu_count": os.cpu_count()}
+
+
+def pmc_traffic_for(dom):
+    """(HBM bytes per launch of the dominant kernel, provenance) from profiles/pmc_traffic.json -- separate rocprofv3 --pmc
+    passes of an earlier run of this command, not live counters.  REFUSED (None, reason) when it cannot describe the
+    kernels in the library that is running now: the profile must name the kernel, the kernel must still be in
+    libcmtfpls.so, and the source file it was compiled from must hash to what the profile recorded."""
+    import hashlib
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc_file):
+        return None, None
+    doc = json.load(open(pmc_file))
+    key = {"mode0_contract": "contract_vec_kernel", "score": "score_kernel"}[dom]
+    if key not in doc.get("kernels", {}):
+        return None, f"profiles/pmc_traffic.json has no entry for {key}"
+    from cmtf_pls_amd import _lib
+    try:
+        in_lib = key.encode() in open(_lib.LIB_PATH, "rb").read()
+    except OSError:
+        in_lib = False
+    if not in_lib:
+        return None, f"refused: {key} of profiles/pmc_traffic.json is not a kernel of the current libcmtfpls.so"
+    for rel, want in (doc.get("source_sha256") or {}).items():
+        path = os.path.join(ROOT, rel)
+        have = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+        if have != want:
+            return None, f"refused: {rel} changed since profiles/pmc_traffic.json ({doc.get('round')}) was taken; re-run tools/pmc_traffic.py"
+    if not doc.get("source_sha256"):
+        return None, "refused: profiles/pmc_traffic.json records no source hashes (taken before round 3)"
+    return (doc["kernels"][key]["hbm_bytes_per_launch"],
+            f"profiles/pmc_traffic.json ({doc.get('round', '?')}; separate rocprofv3 --pmc passes of this command, sources unchanged since)")
+
+
+def north_star_leg(be, eng_cls, device, steps, repeats, timer):
+    """BASELINE.json north_star workload on ONE GPU: X 262144 x 256 x 256 f32 (68.7 GB), Y 262144 x 32, R = 10 -- direct
+    NIPALS iterations (two full reads of X each) replayed as a HIP graph, then the component's deflation sweeps.  Returns
+    None when less than 150 GB of HBM are free."""
+    from cmtf_pls_amd.synthetic import synthetic_shard_device
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        return {"skipped": f"{free / 1e9:.0f} GB of HBM free, 150 GB needed"}
+    I, J, K, M, R = 262144, 256, 256, 32, 10
+    X, Y = synthetic_shard_device((I, J, K), M, R, error=0.1, seed=215, device=device)
+    eng = eng_cls(be, None)
+    t0 = time.perf_counter()
+    run = eng.begin([X], Y, R, coupled=False)          # centres X in place: no second copy of the 68.7 GB
+    torch.cuda.synchronize()
+    pre_s = time.perf_counter() - t0
+    run.start_component(0)
+    it = 0
+    for _ in range(3):
+        run.iterate(it)
+        it += 1
+    xbytes = I * J * K * X.element_size()
+    # eager windows with events (per-sweep rates), then graph-replay windows (the it/s figure)
+    for n in timer.records:
+        timer.records[n] = []
+    timer.on = True
+    for _ in range(max(2, steps // 2)):
+        run.iterate(it)
+        it += 1
+    torch.cuda.synchronize()
+    timer.on = False
+    sweeps = {}
+    for name, src in (("contraction", "mode0_contract_yq"), ("score", "score_gram")):
+        if timer.records[src]:
+            ms = timer.mean_ms(src)
+            sweeps[name] = {"ms": ms, "GBps": xbytes / ms / 1e6, "frac": xbytes / ms / 1e6 / HBM_PEAK_GBPS}
+    run.use_graphs = True
+    for _ in range(4):
+        run.iterate(it)
+        it += 1
+    wins = []
+    for _ in range(max(1, repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run.iterate(it)
+            it += 1
+        torch.cuda.synchronize()
+        wins.append(time.perf_counter() - t0)
+    med = float(np.median(wins))
+    # the deflation of the component: the fit's own fused form (X -= t w^T, then the next component's first contraction
+    # from the same registers) through finish_component, and the plain sweep; 2 * I * P * s algorithmic bytes each
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run.finish_component(0)
+    e1.record()
+    torch.cuda.synchronize()
+    finish_ms = e0.elapsed_time(e1)
+    blk = run.blocks[0]
+    tz = torch.zeros(I, dtype=torch.float64, device=device)
+    Zs = torch.empty(J * K, dtype=torch.float64, device=device)
+    q1 = torch.ones(M, dtype=torch.float64, device=device)
+    defl = {}
+    for name, fn in (("deflate", lambda: be.deflate(run.X2[0], blk.A, blk.B, tz, run.wA[0], run.wB[0])),
+                     ("deflate_contract_yq", lambda: be.deflate_contract_yq(run.X2[0], blk.A, blk.B, tz, run.wA[0], run.wB[0], run.Y, q1, False, out=Zs))):
+        ms = timer.time_calls(fn, n=3, warm=1)
+        defl[name] = {"ms": ms, "GBps": 2 * xbytes / ms / 1e6, "frac": 2 * xbytes / ms / 1e6 / HBM_PEAK_GBPS}
+    out = {"workload": "BASELINE configs[4] on ONE GPU: tPLS direct NIPALS iteration, X 262144x256x256 f32 (68.7 GB, f64 accumulation), "
+                       "Y 262144x32, R=10, noise 0.1", "it_per_s": steps / med, "ms_per_step": med / steps * 1e3,
+           "it_per_s_min": steps / max(wins), "it_per_s_max": steps / min(wins), "steps": steps, "repeats": len(wins),
+           "hip_graphs": bool(run.use_graphs), "x_reads_per_step": 2, "alg_GB_per_step": 2 * xbytes / 1e9,
+           "end_to_end_GBps": 2 * xbytes / (med / steps) / 1e9, "sweeps": sweeps, "deflation": defl,
+           "deflation_frac_of_hbm_peak": defl["deflate"]["frac"], "finish_component_ms": finish_ms, "preprocess_s": pre_s,
+           "target": ">= 50 it/s, >= 40 % of the HBM roofline on the deflation (BASELINE.json north_star)"}
+    del run, X, Y
+    torch.cuda.empty_cache()
+    return out
 
 
 def measure_ceilings(be, timer, scratch, src, row_bytes):
@@ -277,14 +390,24 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 
-    # (1) eager pass with HIP events bracketing every kernel launch (roofline figures come from here;
-    #     events cannot bracket kernels inside a graph replay)
+    # (1) eager passes with HIP events bracketing every kernel launch (roofline figures come from here;
+    #     events cannot bracket kernels inside a graph replay).  `--repeats` windows of EXACTLY `--steps` iterations
+    #     each; every window contributes its own per-kernel mean, the report carries median / min / max over windows
+    reps = max(1, args.repeats)
     for _ in range(args.warmup):
         run.iterate(state["it"])
         state["it"] += 1
-    eager_elapsed = timed(args.steps, events=True)
-    elapsed = eager_elapsed
-    # (2) the same K iterations with the launch sequence replayed as a HIP graph (the headline when
+    eager_windows, kernel_windows = [], {n: [] for n in timer.records}
+    for _ in range(reps):
+        for n in timer.records:
+            timer.records[n] = []
+        eager_windows.append(timed(args.steps, events=True))
+        for n in timer.records:
+            if timer.records[n]:
+                kernel_windows[n].append(timer.mean_ms(n))
+    eager_elapsed = float(np.median(eager_windows))
+    elapsed, windows = eager_elapsed, eager_windows
+    # (2) the same windows with the launch sequence replayed as a HIP graph (the headline when
     #     capture works: identical kernels, ~1 host call per iteration instead of ~20 launches)
     if args.graphs:
         try:
@@ -293,11 +416,12 @@ def main():
                 run.iterate(state["it"])
                 state["it"] += 1
             if run.use_graphs:
-                elapsed = timed(args.steps, events=False)
+                windows = [timed(args.steps, events=False) for _ in range(reps)]
+                elapsed = float(np.median(windows))
         except Exception as e:                     # keep the eager figure rather than lose the run
             run.use_graphs = False
             run._graph_error = repr(e)
-            elapsed = eager_elapsed
+            elapsed, windows = eager_elapsed, eager_windows
     graphs_used, graph_error = run.use_graphs, run._graph_error
     run.finish_component(0)                        # exercises the deflation sweep once (timed below by events)
 
@@ -305,13 +429,15 @@ def main():
     xbytes = rows * J * K * es                     # ALGORITHMIC bytes of one X read on this rank
     kern = {}
     # "mode0_contract" / "score" report whichever form the iteration launched (fused when its events exist)
-    fused = bool(timer.records["mode0_contract_yq"]) and bool(timer.records["score_gram"])
+    fused = bool(kernel_windows["mode0_contract_yq"]) and bool(kernel_windows["score_gram"])
     for name, src, nbytes in (("mode0_contract", "mode0_contract_yq" if fused else "mode0_contract", xbytes),
                               ("score", "score_gram" if fused else "score", xbytes)):
-        ms = timer.mean_ms(src)
-        kern[name] = {"ms": ms, "alg_GB": nbytes / 1e9, "GBps": nbytes / ms / 1e6 if ms else None, "entry": src}
+        w = kernel_windows[src]
+        ms = float(np.median(w))
+        kern[name] = {"ms": ms, "ms_min": min(w), "ms_max": max(w), "windows": len(w), "alg_GB": nbytes / 1e9,
+                      "GBps": nbytes / ms / 1e6 if ms else None, "entry": src}
     for name in (("rank1", "q_update") if fused else ("rank1", "gram_tn", "rowdot")):
-        kern[name] = {"ms": timer.mean_ms(name)}
+        kern[name] = {"ms": float(np.median(kernel_windows[name])) if kernel_windows[name] else None}
     # the read-modify-write sweeps of the fit path (2 * I * P * s algorithmic bytes each), HIP events over 5 launches
     blk = run.blocks[0]
     tz = torch.zeros(rows, dtype=torch.float64, device=device)
@@ -342,17 +468,12 @@ def main():
             if "GBps" in kern[name]:
                 kern[name]["frac_of_measured_rmw"] = kern[name]["GBps"] / ceilings["rmw_GBps"]
 
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # from separate rocprofv3 --pmc passes (not live)
-    if os.path.exists(pmc_file) and (I_total, J, K, world) == (65536, 128, 128, 1):
-        doc = json.load(open(pmc_file))
-        key = {"mode0_contract": "contract_vec_kernel", "score": "score_kernel"}[dom]
-        if key in doc["kernels"]:
-            traffic = doc["kernels"][key]["hbm_bytes_per_launch"]
-            traffic_src = f"profiles/pmc_traffic.json ({doc.get('round', 'r01')}; separate rocprofv3 --pmc passes, not this run)"
+    traffic, traffic_src = pmc_traffic_for(dom) if (I_total, J, K, world) == (65536, 128, 128, 1) else (None, None)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": xbytes, "avg_launch_ms": kern[dom]["ms"],
+                "avg_launch_ms_is": f"median over {kern[dom]['windows']} windows of the per-window mean (HIP events, launch stream)",
+                "avg_launch_ms_min_max": [kern[dom]["ms_min"], kern[dom]["ms_max"]],
                 "peak_measured_read": ceilings["read_GBps"] if ceilings else None,
                 "peak_measured_rmw": ceilings["rmw_GBps"] if ceilings else None,
                 "peak_measured_copy": ceilings["copy_GBps"] if ceilings else None,
@@ -422,7 +543,23 @@ def main():
             mfma[name] = {"ms": ms, "alg_GB": xbytes / 1e9, "GBps": xbytes / ms / 1e6, "TFLOPs": flops / ms / 1e9,
                           "mfma_utilisation": flops / ms / 1e9 / F64_MFMA_PEAK_TF,
                           "frac_of_measured_read": xbytes / ms / 1e6 / ceilings["read_GBps"] if ceilings else None}
-        mfma["mttkrp"]["note"] = "flops count the 16-wide MFMA tile the R=10 components occupy"
+        # the tile-based figures above count every MFMA issued; the USEFUL share is R / 16ceil(R/16) of the MTTKRP's tile
+        # columns and M / 16ceil(M/16) of the S build's tile rows
+        for name, useful in (("xcov", M / (16.0 * ((M + 15) // 16))), ("mttkrp", R / (16.0 * ((R + 15) // 16)))):
+            mfma[name]["useful_tile_fraction"] = useful
+            mfma[name]["useful_TFLOPs"] = mfma[name]["TFLOPs"] * useful
+            mfma[name]["useful_flop_utilisation"] = mfma[name]["mfma_utilisation"] * useful
+        mfma["mttkrp"]["note"] = "TFLOPs / mfma_utilisation count the 16-wide MFMA tile the R=10 components occupy; useful_* scale by R/16"
+
+    north = None
+    if world == 1 and not args.no_north_star and (I_total, J, K, M) == (65536, 128, 128, 16):
+        del X, Y
+        if not args.no_fit:
+            del st, sx, sm, X2, S, Mo
+        try:
+            north = north_star_leg(be, NipalsEngine, device, args.north_star_steps, min(args.repeats, 3), timer)
+        except Exception as e:                     # never lose the headline line to the extra leg
+            north = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -434,6 +571,8 @@ def main():
         out = {
             "metric": "nipals_iters_per_sec", "value": args.steps / elapsed, "unit": "it/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": len(windows), "value_min": args.steps / max(windows), "value_max": args.steps / min(windows),
+            "value_is": f"median of {len(windows)} timed windows of exactly {args.steps} iterations each",
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg_name}: tPLS direct NIPALS iteration, X {I_total}x{J}x{K} f32 "
@@ -441,8 +580,10 @@ def main():
                        "rows_per_gpu": rows, "parallelism": f"sample-mode shard x{world}" if world > 1 else "single GPU",
                        "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
                        "x_reads_per_step": 2, "hip_graphs": bool(graphs_used), "graph_error": graph_error,
-                       "eager_ms_per_step": eager_elapsed / args.steps * 1e3},
+                       "eager_ms_per_step": eager_elapsed / args.steps * 1e3,
+                       "eager_ms_per_step_min_max": [min(eager_windows) / args.steps * 1e3, max(eager_windows) / args.steps * 1e3]},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "collectives": comm_info, "mfma": mfma, "fit": fit_info,
+            "north_star": north,
         }
         print(json.dumps(out), flush=True)
     if backend:

@@ -70,6 +70,8 @@ SIGNATURES = {
     "cmtfpls_y_deflate_f64": (c_int, [_P, c_int, c_int, c_int64, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_sum_f64": (c_int, [_P, c_int64, _P, _P]),
     "cmtfpls_normal_solve_f64": (c_int, [_P, _P, c_int, _P, c_int, _P]),
+    "cmtfpls_normal_solve_workspace_bytes": (c_size_t, [c_int]),
+    "cmtfpls_normal_solve_ws_f64": (c_int, [_P, _P, c_int, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_unit_upper_solve_rows_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "cmtfpls_kr_gram_f64": (c_int, [_P, c_int, c_int, _P, c_int, c_double, _P]),
     "cmtfpls_khatri_rao_f64": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),

@@ -287,7 +287,12 @@ class HipBackend:
         k = G.shape[0]
         assert G.is_contiguous() and G.shape == (k, k) and g.numel() == k
         b = out if out is not None else self.empty(k)
-        _lib.check(self.lib.cmtfpls_normal_solve_f64(_ptr(G), _ptr(g), k, _ptr(b), 1, self._stream()), "normal_solve")
+        if k <= 64:
+            _lib.check(self.lib.cmtfpls_normal_solve_f64(_ptr(G), _ptr(g), k, _ptr(b), 1, self._stream()), "normal_solve")
+        else:                                                   # more than 64 components: the matrix in a workspace
+            ws = self._workspace("normal_solve", self.lib.cmtfpls_normal_solve_workspace_bytes(k))
+            _lib.check(self.lib.cmtfpls_normal_solve_ws_f64(_ptr(G), _ptr(g), k, _ptr(b), 1, _ptr(ws), ws.numel(), self._stream()),
+                       "normal_solve")
         return b
 
     def unit_upper_solve_rows(self, M: torch.Tensor, U: torch.Tensor, shift: Optional[torch.Tensor] = None,

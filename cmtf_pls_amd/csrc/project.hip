@@ -134,13 +134,21 @@ static int run_project_rows(const T* X, int64_t I, int A, int B, int R, const do
   const int64_t stride = (int64_t)kProjThreads * V;
   const int64_t nv = (P + stride - 1) / stride;
   // B % V == 0 (a vector never straddles a j boundary); stride % B == 0 (k constant per lane); 16 vectors per lane at most
-  if ((B % V) != 0 || (stride % B) != 0 || nv > 16 || lds > 64 * 1024 || (reinterpret_cast<uintptr_t>(X) & 15) != 0) {
+  // (LDS: the loadings plus the 64 static bytes of `red`; beyond 64 KB the dynamic limit is raised per instance below)
+  constexpr size_t kProjLdsMax = 144 * 1024;
+  if ((B % V) != 0 || (stride % B) != 0 || nv > 16 || lds > kProjLdsMax || (reinterpret_cast<uintptr_t>(X) & 15) != 0) {
     set_error("project_rows: shape outside the row-in-registers form; use the score_deflate passes");
     return CMTFPLS_EUNSUPPORTED;
   }
   const int grid = (int)(I < 4096 ? I : 4096);
   const dim3 g(grid), b(kProjThreads);
-#define PRL(NVV) hipLaunchKernelGGL((project_rows_kernel<T, NVV>), g, b, lds, st, X, I, A, B, R, WA, WB, mean, scores, ld)
+#define PRL(NVV)                                                                                                         \
+  do {                                                                                                                   \
+    if (lds + 64 > 64 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(project_rows_kernel<T, NVV>),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+    hipLaunchKernelGGL((project_rows_kernel<T, NVV>), g, b, lds, st, X, I, A, B, R, WA, WB, mean, scores, ld);           \
+  } while (0)
   if (nv <= 2) PRL(2); else if (nv <= 4) PRL(4); else if (nv <= 8) PRL(8); else PRL(16);
 #undef PRL
   return check_launch("project_rows");

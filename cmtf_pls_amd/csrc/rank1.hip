@@ -15,17 +15,26 @@
 namespace cmtfpls {
 
 constexpr int kTile = 16;
-constexpr int kMaxTiles = 64;   // n <= 1024
+constexpr int kMaxTiles = 256;  // n <= 4096 (round 3: the control block is sized by the call, not by this bound)
 constexpr int kMaxSteps = 48;
 
+// Control block at the head of the workspace: four flags, then trace[(kMaxSteps + 2) x nt] (trace[s * nt + tile]: the
+// diagonal-tile partial traces of G_s) and fro[2 x nt^2] (fro[(s & 1) * nt^2 + tile]: per-tile sums of squares of G_s,
+// |G_s|_F^2 = tr(G_s^2)), nt = ceil(n / 16).
 struct Rank1Ctl {
-  double trace[kMaxSteps + 2][kMaxTiles];  // trace[s][tile]: diagonal-tile partial traces of G_s
-  double fro[2][kMaxTiles * kMaxTiles];    // fro[s & 1][tile]: per-tile sums of squares of G_s (|G_s|_F^2 = tr(G_s^2))
   int done;                                // set once G is numerically rank one
   int final_buf;                           // which ping-pong buffer holds the final G
   int steps_used;                          // squarings actually computed
   int last_step;                           // >= 0: the output of this step is the final G (set by that step itself)
+  double pad[6];                           // the arrays start 64 bytes in
 };
+__host__ __device__ __forceinline__ size_t rank1_ctl_bytes(int nt) {
+  return sizeof(Rank1Ctl) + ((size_t)(kMaxSteps + 2) * nt + 2 * (size_t)nt * nt) * sizeof(double);
+}
+__device__ __forceinline__ double* ctl_trace(Rank1Ctl* c, int nt, int step) { return reinterpret_cast<double*>(c + 1) + (size_t)step * nt; }
+__device__ __forceinline__ double* ctl_fro(Rank1Ctl* c, int nt, int which) {
+  return reinterpret_cast<double*>(c + 1) + (size_t)(kMaxSteps + 2) * nt + (size_t)which * nt * nt;
+}
 
 __device__ __forceinline__ double pow2_scale_from_trace(const double* parts, int nt, double* tr_out) {
   double tr = 0.0;
@@ -102,8 +111,8 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
     // final.  (A workgroup of step s0 itself may see last_step == s0, written by a sibling: it still computes.)
     const int last_in = (&ctl->last_step)[zero];
     const int done_in = (&ctl->done)[zero] | ((last_in >= 0 && last_in < step) ? 1 : 0);
-    const double* fp = ctl->fro[(step - 1) & 1];
-    const double trv = ctl->trace[step - 1][(tid < nt) ? tid : 0];
+    const double* fp = ctl_fro(ctl, nt, (step - 1) & 1);
+    const double trv = ctl_trace(ctl, nt, step - 1)[(tid < nt) ? tid : 0];   // nt <= 256 = the workgroup size
     // |G_{s-1}|_F^2 from the per-tile sums the previous step left (fixed order: bit-reproducible)
     double f = fp[(tid < nt * nt) ? tid : 0];
     if (tid < nt) tr_s[tid] = trv;
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
     sq = wave_sum(sq);
     if ((tid & 63) == 0) fsum[tid >> 6] = sq;   // fsum is free: its readers passed two barriers since
     __syncthreads();
-    if (tid == 0) ctl->fro[step & 1][blockIdx.y * nt + blockIdx.x] = ((fsum[0] + fsum[1]) + fsum[2]) + fsum[3];
+    if (tid == 0) ctl_fro(ctl, nt, step & 1)[blockIdx.y * nt + blockIdx.x] = ((fsum[0] + fsum[1]) + fsum[2]) + fsum[3];
   }
   if (blockIdx.x == blockIdx.y) {
     if (tx == ty) diag[tx] = (i0 + ty < n) ? cacc : 0.0;
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
     if (tid == 0) {
       double t = 0.0;
       for (int l = 0; l < kTile; ++l) t += diag[l];
-      ctl->trace[step][blockIdx.x] = t;
+      ctl_trace(ctl, nt, step)[blockIdx.x] = t;
     }
   }
 }
@@ -341,7 +350,7 @@ extern "C" {
 size_t cmtfpls_rank1_workspace_bytes(int A, int B) {
   if (A <= 0 || B <= 0) return 0;
   const size_t n = (size_t)(A < B ? A : B), k = (size_t)(A < B ? B : A);
-  return align_up(sizeof(Rank1Ctl), 256) + 3 * align_up(n * n * sizeof(double), 256) +
+  return align_up(rank1_ctl_bytes((int)((n + kTile - 1) / kTile)), 256) + 3 * align_up(n * n * sizeof(double), 256) +
          align_up((size_t)A * B * sizeof(double), 256) + align_up(n * sizeof(double), 256) + align_up(k * sizeof(double), 256);
 }
 
@@ -349,14 +358,15 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
                       int n_squarings, void* ws, size_t ws_bytes, void* stream) {
   if (!Z || !wA || !wB || A <= 0 || B <= 0) { set_error("rank1: bad argument"); return CMTFPLS_EINVAL; }
   const int n = A < B ? A : B, k = A < B ? B : A;
-  if (n > kTile * kMaxTiles) { set_error("rank1: min(A, B) > 1024 unsupported"); return CMTFPLS_EUNSUPPORTED; }
+  if (n > kTile * kMaxTiles) { set_error("rank1: min(A, B) > 4096 unsupported"); return CMTFPLS_EUNSUPPORTED; }
+  if ((size_t)n * sizeof(double) > 64 * 1024) { set_error("rank1: seed exceeds the LDS"); return CMTFPLS_EUNSUPPORTED; }
   if (n_squarings < 1) n_squarings = 1;
   if (n_squarings > kMaxSteps) n_squarings = kMaxSteps;
   if (!ws || ws_bytes < cmtfpls_rank1_workspace_bytes(A, B)) { set_error("rank1: workspace too small"); return CMTFPLS_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   char* p = static_cast<char*>(ws);
   Rank1Ctl* ctl = reinterpret_cast<Rank1Ctl*>(p);
-  p += align_up(sizeof(Rank1Ctl), 256);
+  p += align_up(rank1_ctl_bytes((n + kTile - 1) / kTile), 256);
   double* buf0 = reinterpret_cast<double*>(p);
   p += align_up((size_t)n * n * sizeof(double), 256);
   double* buf1 = reinterpret_cast<double*>(p);

@@ -72,6 +72,67 @@ __global__ __launch_bounds__(kSolveMax) void normal_solve_kernel(const double* _
   if (i < k) b[(int64_t)i * incb] = y[i] * d[i];
 }
 
+// The same solve for 64 < k <= kSolveBigMax (round 3; the reference's lstsq has no limit on n_components, tpls.py:110-112):
+// identical algorithm and pivot rule, the equilibrated matrix in a k x (k + 1) global-memory workspace instead of the
+// LDS, one 256-thread workgroup, thread t owning rows t, t + 256, ...; the two triangular solves are column sweeps with
+// one barrier per column.  Only fits with more than 64 components come here: a few hundred microseconds per component.
+constexpr int kSolveBigMax = 1024;
+__global__ __launch_bounds__(256) void normal_solve_big_kernel(const double* __restrict__ G, const double* __restrict__ g, int k,
+                                                               double* __restrict__ b, int incb, double* __restrict__ Aw) {
+  const int ld = k + 1;
+  double* d = Aw + (size_t)k * ld;
+  double* y = d + k;
+  double* depf = y + k;                       // 1.0 = dependent column
+  __shared__ double s_piv;
+  const int t = threadIdx.x;
+  for (int i = t; i < k; i += 256) {
+    const double gii = G[(int64_t)i * k + i];
+    d[i] = (gii > 0.0 && isfinite(gii)) ? 1.0 / sqrt(gii) : 0.0;
+    depf[i] = 0.0;
+  }
+  __syncthreads();
+  for (int i = t; i < k; i += 256) {
+    for (int j = 0; j < k; ++j) Aw[(size_t)i * ld + j] = G[(int64_t)i * k + j] * d[i] * d[j];
+    y[i] = g[i] * d[i];
+  }
+  __syncthreads();
+  const double tiny = (double)k * 2.220446049250313e-16;
+  for (int c = 0; c < k; ++c) {
+    if (t == 0) s_piv = Aw[(size_t)c * ld + c];
+    __syncthreads();
+    const double piv = s_piv;
+    const bool ok = piv > tiny;
+    const double l = ok ? sqrt(piv) : 1.0;
+    for (int i = c + t; i < k; i += 256) {
+      if (i == c) { Aw[(size_t)c * ld + c] = l; if (!ok) depf[c] = 1.0; }
+      else Aw[(size_t)i * ld + c] = ok ? Aw[(size_t)i * ld + c] / l : 0.0;
+    }
+    __syncthreads();
+    if (ok)
+      for (int i = c + 1 + t; i < k; i += 256) {
+        const double lic = Aw[(size_t)i * ld + c];
+        for (int j = c + 1; j <= i; ++j) Aw[(size_t)i * ld + j] -= lic * Aw[(size_t)j * ld + c];
+      }
+    __syncthreads();
+  }
+  // forward L z = y (column sweep), backward L^T x = z (row r of L^T is column r of L)
+  for (int r = 0; r < k; ++r) {
+    if (t == 0) y[r] = (depf[r] != 0.0) ? 0.0 : y[r] / Aw[(size_t)r * ld + r];
+    __syncthreads();
+    const double yr = y[r];
+    for (int j = r + 1 + t; j < k; j += 256) y[j] -= Aw[(size_t)j * ld + r] * yr;
+    __syncthreads();
+  }
+  for (int r = k - 1; r >= 0; --r) {
+    if (t == 0) y[r] = (depf[r] != 0.0) ? 0.0 : y[r] / Aw[(size_t)r * ld + r];
+    __syncthreads();
+    const double yr = y[r];
+    for (int j = t; j < r; j += 256) y[j] -= Aw[(size_t)r * ld + j] * yr;
+    __syncthreads();
+  }
+  for (int i = t; i < k; i += 256) b[(int64_t)i * incb] = y[i] * d[i];
+}
+
 // rows of T solve  T (I + triu(U, 1)) = M - 1 shift^T:  t_a = (m_a - shift_a) - sum_{j < a} t_j U[j][a]   (one thread per
 // row, in place).  shift (R, nullable): the centring of an UNCENTRED MTTKRP, (X - 1 mean^T) W = X W - 1 (mean^T W)^T, so
 // that transform / predict read the caller's X once and never write a centred copy.  nan_flag (nullable, zeroed by the
@@ -147,8 +208,22 @@ extern "C" {
 
 int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b, int incb, void* stream) {
   if (!G || !g || !b || k <= 0 || incb <= 0) { set_error("normal_solve: bad argument"); return CMTFPLS_EINVAL; }
-  if (k > kSolveMax) { set_error("normal_solve: more than 64 components"); return CMTFPLS_EUNSUPPORTED; }
+  if (k > kSolveMax) { set_error("normal_solve: more than 64 components; use cmtfpls_normal_solve_ws_f64"); return CMTFPLS_EUNSUPPORTED; }
   hipLaunchKernelGGL(normal_solve_kernel, dim3(1), dim3(kSolveMax), 0, (hipStream_t)stream, G, g, k, b, incb);
+  return check_launch("normal_solve");
+}
+
+size_t cmtfpls_normal_solve_workspace_bytes(int k) {
+  if (k <= kSolveMax || k > kSolveBigMax) return 0;
+  return ((size_t)k * (k + 1) + 3 * (size_t)k) * sizeof(double);
+}
+
+int cmtfpls_normal_solve_ws_f64(const double* G, const double* g, int k, double* b, int incb, void* ws, size_t ws_bytes, void* stream) {
+  if (k <= kSolveMax) return cmtfpls_normal_solve_f64(G, g, k, b, incb, stream);
+  if (!G || !g || !b || incb <= 0) { set_error("normal_solve: bad argument"); return CMTFPLS_EINVAL; }
+  if (k > kSolveBigMax) { set_error("normal_solve: more than 1024 components"); return CMTFPLS_EUNSUPPORTED; }
+  if (!ws || ws_bytes < cmtfpls_normal_solve_workspace_bytes(k)) { set_error("normal_solve: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  hipLaunchKernelGGL(normal_solve_big_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, g, k, b, incb, static_cast<double*>(ws));
   return check_launch("normal_solve");
 }
 

@@ -72,6 +72,31 @@ def split_trailing(shape: Sequence[int]):
     return int(trailing[0]), int(np.prod(trailing[1:]))
 
 
+# Hard limits of the kernel set.  The reference has none (tpls.py:84-90,110-112): they are checked BEFORE
+# the first sweep over X, not discovered after a centring pass or 64 components of work.
+MAX_COMPONENTS = 1024          # cmtfpls_normal_solve_ws_f64: the (a+1) x (a+1) normal equations in one workgroup
+MAX_RANK1_SIDE = 4096          # cmtfpls_rank1_f64: min(J, K) of an order-3 block (Gram squaring of the smaller side)
+MAX_TENSOR_MODE = 1024         # cmtfpls_rank1_tensor_f64: every trailing mode of an order-4/5 block
+MAX_ORDER = 5
+
+
+def validate_limits(shapes, n_components: int) -> None:
+    """Raise ValueError / NotImplementedError for a fit the kernels cannot finish, before any work is done."""
+    if n_components < 1:
+        raise ValueError("n_components must be >= 1")
+    if n_components > MAX_COMPONENTS:
+        raise ValueError(f"n_components = {n_components} exceeds this engine's limit of {MAX_COMPONENTS} "
+                         "(the inner regression solves the (a+1) x (a+1) normal equations in one workgroup)")
+    for shape in shapes:
+        order = len(shape)
+        if order > MAX_ORDER:
+            raise NotImplementedError("X blocks of order > 5 are not supported")
+        if order == 3 and min(shape[1:]) > MAX_RANK1_SIDE:
+            raise ValueError(f"X block {tuple(shape)}: min(J, K) = {min(shape[1:])} exceeds the rank-1 kernel's limit of {MAX_RANK1_SIDE}")
+        if order >= 4 and max(shape[1:]) > MAX_TENSOR_MODE:
+            raise ValueError(f"X block {tuple(shape)}: a trailing mode exceeds the order-{order} rank-1 kernel's limit of {MAX_TENSOR_MODE}")
+
+
 @dataclass
 class BlockState:
     shape: tuple                     # local shape (I_local, d1, d2, ...)
@@ -286,11 +311,13 @@ class NipalsEngine:
             WB = be.khatri_rao(WB, L)
         return loads[0], WB
 
-    def reconstruct(self, state: FitState, block: int = 0, rows: Optional[slice] = None) -> Optional[torch.Tensor]:
+    def reconstruct(self, state: FitState, block: int = 0, rows: Optional[slice] = None,
+                    dtype: Optional[torch.dtype] = None) -> Optional[torch.Tensor]:
         """Rows of factors_to_tensor(X_factors) + X_mean (util.py:18-20 with tpls.py:188-189 / cmtf.py:233-237) for
-        one block, formed on the GPU in the block's storage type: Xhat = T (W_1 (.) W_2 (.) ...)^T + mean with the
-        Khatri-Rao operand never materialised (cmtfpls_recon_*).  None when the backend / shape has no device form
-        (the caller falls back to the host einsum)."""
+        one block, formed on the GPU in `dtype` (default: the block's storage type; the estimators ask for float64 when
+        they return a host array, as the reference does): Xhat = T (W_1 (.) W_2 (.) ...)^T + mean with the Khatri-Rao
+        operand never materialised (cmtfpls_recon_*).  None when the backend / shape has no device form (the caller
+        falls back to the host einsum)."""
         be = self.be
         if not hasattr(be, "recon"):
             return None
@@ -298,7 +325,7 @@ class NipalsEngine:
         with self.device_ctx():
             T = state.T if rows is None else state.T[rows]
             WA, WB = self._kr_operands(blk, state.n_components)
-            out = be.empty(T.shape[0], blk.A * blk.B, dtype=blk.dtype or torch.float64)
+            out = be.empty(T.shape[0], blk.A * blk.B, dtype=dtype or blk.dtype or torch.float64)
             if T.shape[0] == 0 or be.recon(T, WA, WB, blk.mean, out) is None:
                 return None
             return out.view((T.shape[0],) + tuple(blk.shape[1:]))
@@ -367,6 +394,7 @@ class FitRun:
         if algorithm == "xcov" and Y.shape[1] > 64:
             algorithm = "direct"                                  # S = X^T Y is built for M <= 64 responses
         self.algorithm = algorithm
+        validate_limits([tuple(X.shape) for X in Xs], n_components)   # before the first sweep touches X
         self.eng, self.Xs, self.Y, self.R, self.coupled = eng, Xs, Y, n_components, coupled
         R = n_components
         I, M = Y.shape

@@ -112,23 +112,36 @@ class _EstimatorBase(Mapping):
 
     def _reconstruct(self, block: int, factors, mean, rows=None, device: bool = False):
         """factors_to_tensor(factors) + mean (tpls.py:188-189, cmtf.py:233-237) through the GPU kernel; `rows` (a
-        slice) restricts it to a row block and `device=True` returns the device tensor in the storage type instead
-        of a float64 NumPy array -- at 65536 x 128 x 128 the reference's host form is an 8.6 GB float64 einsum."""
-        rec = self._get_engine().reconstruct(self._state, block, rows)
-        if rec is None:                                                    # no device form for this shape / backend
-            from .util import factors_to_tensor
-            f = [factors[0] if rows is None else factors[0][rows]] + list(factors[1:])
-            out = factors_to_tensor(f) + mean
-            return torch.from_numpy(out) if device else out
+        slice) restricts it to a row block and `device=True` returns the device tensor IN THE STORAGE TYPE (f32 storage:
+        entries rounded to f32, ~6e-8 relative) instead of a float64 NumPy array holding the exact f64 reconstruction --
+        at 65536 x 128 x 128 the reference's host form is an 8.6 GB float64 einsum."""
+        eng = self._get_engine()
         if device:
-            return rec
-        if rec.dtype == torch.float64 or rec.numel() * 8 < (64 << 20):
-            return rec.double().cpu().numpy()
-        out = np.empty(tuple(rec.shape), dtype=np.float64)         # float64 on the host as the reference returns it: widen on the
-        rows = max(1, (256 << 20) // max(rec[0].numel() * 8, 1))   # device row block by row block (a host astype of 4.3 GB costs seconds)
-        for r in range(0, rec.shape[0], rows):
-            out[r:r + rows] = rec[r:r + rows].double().cpu().numpy()
-        return out
+            rec = eng.reconstruct(self._state, block, rows)
+            if rec is not None:
+                return rec
+        else:
+            # the host array is float64 like the reference's (tpls.py:188-189): the kernel writes float64 row blocks
+            # (<= 256 MB each on the device) straight from the f64 factors -- no rounding to the storage type on the way
+            n = self._state.T.shape[0]
+            lo, hi, step = (rows or slice(None)).indices(n)
+            if step == 1:
+                trailing = tuple(self._state.blocks[block].shape[1:])
+                per_row = int(np.prod(trailing)) * 8
+                chunk = max(1, (256 << 20) // max(per_row, 1))
+                out, ok = np.empty((max(hi - lo, 0),) + trailing, dtype=np.float64), True
+                for r in range(lo, hi, chunk):
+                    rec = eng.reconstruct(self._state, block, slice(r, min(r + chunk, hi)), dtype=torch.float64)
+                    if rec is None:
+                        ok = False
+                        break
+                    out[r - lo: r - lo + rec.shape[0]] = rec.cpu().numpy()
+                if ok and hi > lo:
+                    return out
+        from .util import factors_to_tensor                                  # no device form for this shape / backend
+        f = [factors[0] if rows is None else factors[0][rows]] + list(factors[1:])
+        out = factors_to_tensor(f) + mean
+        return torch.from_numpy(out) if device else out
 
     def _predict_from_scores(self, scores_dev: torch.Tensor) -> np.ndarray:
         """`X_projection @ coef_ @ Q^T + Y_mean` (tpls.py:143, cmtf.py:177); on the device when the backend has the

@@ -85,6 +85,7 @@ int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_sa
  * once), then one exact pass y = M^T seed, x = M y with Z itself.  info (nullable, 2 doubles):
  * info[0] = 1 if the squaring was seen to converge within n_squarings (else the caller should call
  * again with a larger budget), info[1] = squarings actually computed (budget hint for the next call).
+ * Limit: min(A, B) <= 4096 (round 2: 1024), CMTFPLS_EUNSUPPORTED beyond.
  * normalize: v /= ||v||_2, the vector case `Z / norm(Z)` (tpls.py:84, cmtf.py:98) and
  * `q /= norm(q)` (tpls.py:101); nrm (nullable) receives the norm. */
 size_t cmtfpls_rank1_workspace_bytes(int A, int B);
@@ -275,6 +276,12 @@ int cmtfpls_allreduce_sum_f32(void* comm, float* buf, size_t count, void* stream
  *   cmtf.py:233-237), the Khatri-Rao operand never materialised; mean nullable.  Any shape (16-byte vectors when
  *   B % (16/sizeof(T)) == 0 and `out` is aligned, single elements otherwise). */
 int cmtfpls_normal_solve_f64(const double* G, const double* g, int k, double* b, int incb, void* stream);
+/* normal_solve_ws: the same solve for any k <= 1024 (the reference's lstsq has no limit on n_components,
+ * tpls.py:110-112): k <= 64 is cmtfpls_normal_solve_f64 (ws may be null); beyond, the equilibrated matrix lives in the
+ * caller's workspace (cmtfpls_normal_solve_workspace_bytes(k); 0 for k <= 64) -- same algorithm, same pivot rule. */
+size_t cmtfpls_normal_solve_workspace_bytes(int k);
+int cmtfpls_normal_solve_ws_f64(const double* G, const double* g, int k, double* b, int incb, void* ws, size_t ws_bytes,
+                                void* stream);
 int cmtfpls_unit_upper_solve_rows_f64(double* M, int64_t I, int ld, int R, const double* U, const double* shift, int* nan_flag,
                                       void* stream);
 int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, double scale, void* stream);

@@ -191,10 +191,10 @@ def test_rank1_matches_lapack(be, shape):
     np.testing.assert_allclose(host(wB), fb, rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("shape", [(600, 640), (1024, 1024), (900, 40), (3, 5000)])
+@pytest.mark.parametrize("shape", [(600, 640), (1024, 1024), (900, 40), (3, 5000), (1040, 1500), (2100, 1100)])
 def test_rank1_large(be, shape):
-    """The documented limit min(A, B) <= 1024 (64 x 64 tiles of trace / Frobenius partials) and wide
-    / tall shapes whose larger side is streamed in 256-column panels."""
+    """Sides beyond 1024 (round 3: the control block of trace / Frobenius partials is sized by the call; the limit is
+    min(A, B) <= 4096) and wide / tall shapes whose larger side is streamed in 256-column panels."""
     A, B = shape
     rng = np.random.default_rng(71)
     Z = rng.normal(size=shape) + 6.0 * np.outer(rng.normal(size=A), rng.normal(size=B))
@@ -204,6 +204,13 @@ def test_rank1_large(be, shape):
     np.testing.assert_allclose(host(wA), u, rtol=0, atol=1e-9)
     np.testing.assert_allclose(host(wB), v, rtol=0, atol=1e-9)
     assert host(info)[0] == 1.0
+
+
+def test_rank1_refuses_beyond_its_limit_without_launching(be):
+    from cmtf_pls_amd import _lib
+    wA, wB = be.empty(4100), be.empty(4097)
+    with pytest.raises(_lib.CmtfplsError, match="4096"):
+        be.rank1(be.empty(16), 4100, 4097, wA, wB)            # refused from the sizes alone: Z is never read
 
 
 def test_rank1_tensor_larger_modes(be):

@@ -9,6 +9,7 @@ Run on the GPU box:  python3 tools/pmc_traffic.py [out.json]
 (this process never touches the GPU; rocprofv3 is started with python3 directly after `--`)."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import subprocess
@@ -18,7 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"contract_vec_kernel": 1, "score_kernel": 1, "deflate_kernel": 2, "deflate_rows_kernel": 2,
            "deflate_contract_kernel": 2, "deflate_contract_rows_kernel": 2, "center_kernel": 2, "center_rows_kernel": 2,
            "score_deflate_kernel": 2, "xcov_kernel": 1, "mttkrp_kernel": 1}
-ROUND = "r02"
+ROUND = "r03"
+# bench.py refuses the profile once any of these changed (the kernels it describes are compiled from them)
+SOURCES = ["cmtf_pls_amd/csrc/sweeps.hip", "cmtf_pls_amd/csrc/common.hpp"]
 XBYTES = 65536 * 128 * 128 * 4
 
 
@@ -26,7 +29,7 @@ def one_pass(counter, outdir):
     os.makedirs(outdir, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "p", "--",
-           "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--graphs", "0", "--no-ceilings"]
+           "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--graphs", "0", "--no-ceilings", "--repeats", "1", "--no-north-star"]
     with open(os.path.join(outdir, "run.log"), "w") as log:
         subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT)
     return parse(counter, outdir)
@@ -68,7 +71,8 @@ def main():
             rec["ratio"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes"]
         kernels[key] = rec
     doc = {"round": ROUND, "method": __doc__.split("\n\n")[1].replace("\n", " "), "workload": "cfg2 65536x128x128 f32, 1 GPU",
-           "command": "python3 tools/pmc_traffic.py", "kernels": kernels}
+           "command": "python3 tools/pmc_traffic.py", "kernels": kernels,
+           "source_sha256": {rel: hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest() for rel in SOURCES}}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps({k: round(v.get("ratio", 0), 4) for k, v in kernels.items()}))
 
