@@ -44,6 +44,8 @@ SIGNATURES = {
     "cmtfpls_s_downdate_f64": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "cmtfpls_project_rows_f32": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "cmtfpls_project_rows_f64": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "cmtfpls_project_rows2_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P]),
+    "cmtfpls_project_rows2_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P]),
     "cmtfpls_allreduce_sum_f64": (c_int, [_P, _P, c_size_t, _P]),
     "cmtfpls_allreduce_sum_f32": (c_int, [_P, _P, c_size_t, _P]),
     "cmtfpls_kr_axpy_f64": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),

@@ -334,6 +334,21 @@ class HipBackend:
         _lib.check(rc, "project_rows")
         return out
 
+    def project_rows2(self, X2s, As, Bs, WAs, WBs, means, out: torch.Tensor) -> Optional[torch.Tensor]:
+        """project_rows for TWO COUPLED blocks (lists of two): the sample's row of both blocks in one workgroup, the score
+        of every step the mean of the two masked block scores (cmtf.py:155,206); None outside that form."""
+        I, R = X2s[0].shape[0], WAs[0].shape[1]
+        if X2s[0].dtype != X2s[1].dtype or X2s[1].shape[0] != I:
+            return None
+        assert all(w.is_contiguous() for w in list(WAs) + list(WBs)) and out.stride(1) == 1 and out.shape == (I, R)
+        rc = self._fn("project_rows2", X2s[0])(_ptr(X2s[0]), As[0], Bs[0], _ptr(WAs[0]), _ptr(WBs[0]), _ptr(means[0]),
+                                               _ptr(X2s[1]), As[1], Bs[1], _ptr(WAs[1]), _ptr(WBs[1]), _ptr(means[1]),
+                                               I, R, _ptr(out), out.stride(0), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "project_rows2")
+        return out
+
     def predict_rows(self, S: torch.Tensor, Bm: torch.Tensor, mean: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         """out (I, M) = S (I, R) @ Bm (R, M) + mean: the last line of predict (tpls.py:143) on the device-resident scores."""
         I, R = S.shape

@@ -243,16 +243,27 @@ class NipalsEngine:
             scores = self._project_one_pass(state, Xs, False, centred=False, nan_flag=flag)
             if scores is not None and int(flag.item()) == 0:
                 return scores
-            # a missing value somewhere: the reference's masked sequence -- centre, then R times score with the per-row
-            # rescale and deflate (tpls.py:128-142, missingvals.py:23-38) -- run on every row in registers, from one read
-            # of the uncentred block (one block; coupled blocks share their score per step and keep the passes)
+            if scores is None and state.n_components > 64:
+                return None                                   # (the LDS of project_rows is sized for the usual few components)
+            # a missing value somewhere (or a shape the MTTKRP does not take): the reference's masked sequence -- centre,
+            # then R times score with the per-row rescale, average the coupled blocks' scores and deflate (tpls.py:128-142,
+            # cmtf.py:143-177, missingvals.py:23-38) -- run on every sample in registers, from one read of the uncentred
+            # blocks (one block, or two coupled blocks in one workgroup; more blocks keep the passes)
             be = self.be
-            if scores is not None and len(state.blocks) == 1 and hasattr(be, "project_rows"):
-                blk, I, R = state.blocks[0], Xs[0].shape[0], state.n_components
-                WA, WB = self._kr_operands(blk, R)
+            nb = len(state.blocks)
+            if nb <= 2 and hasattr(be, "project_rows") and all(X.is_contiguous() for X in Xs):
+                I, R = Xs[0].shape[0], state.n_components
+                ops = [self._kr_operands(blk, R) for blk in state.blocks]
                 out = be.empty(I, R)
-                if be.project_rows(Xs[0].view(I, -1), blk.A, blk.B, WA, WB, blk.mean, out) is not None:
-                    return out
+                if nb == 1:
+                    blk = state.blocks[0]
+                    if be.project_rows(Xs[0].view(I, -1), blk.A, blk.B, ops[0][0], ops[0][1], blk.mean, out) is not None:
+                        return out
+                elif hasattr(be, "project_rows2"):
+                    if be.project_rows2([X.view(I, -1) for X in Xs], [b.A for b in state.blocks], [b.B for b in state.blocks],
+                                        [o[0].contiguous() for o in ops], [o[1].contiguous() for o in ops],
+                                        [b.mean for b in state.blocks], out) is not None:
+                        return out
             return None
 
     def _project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool, mixed: bool) -> torch.Tensor:

@@ -240,12 +240,24 @@ int cmtfpls_sum_f64(const double* in, int64_t n, double* out, void* stream);
  * on it -- x - mean (rounded to the storage type, as the centred copy would be), the observation count, and for a = 0..R-1 the
  * masked score t_a = (sum_obs x w_a) * P / n_obs, scores[i*ld + a] = t_a, x -= t_a w_a (rounded to the storage type) --
  * instead of a centring pass and R read + write passes (cmtfpls_score_deflate_*).  WA (A x R), WB (B x R) row-major, mean (P,
- * nullable = 0).  CMTFPLS_EUNSUPPORTED for rows longer than 4096 16-byte vectors, a trailing extent B that does not divide
- * 256 * (16 / sizeof(T)) elements, or R (A + B) doubles beyond 64 KB of LDS: the caller keeps the passes. */
+ * nullable = 0).  A lane holds up to 16 vectors of 16 bytes: rows of up to 4096 vectors run in 256-thread workgroups, rows of
+ * up to 16384 vectors (256 x 256 f32, BASELINE configs[4]) in 1024-thread workgroups of 128 registers per lane.
+ * CMTFPLS_EUNSUPPORTED for longer rows, a trailing extent B that does not divide the workgroup stride (256 or 1024 times
+ * 16 / sizeof(T) elements), or loadings beyond 144 KB of LDS: the caller keeps the passes.
+ * project_rows2: the same for TWO COUPLED blocks sharing the sample mode (ctPLS.transform / predict with missing values,
+ * cmtf.py:143-177,180-210): one workgroup holds the sample's row of both blocks, the score of a step is the mean of the two
+ * masked block scores (np.average, cmtf.py:155,206) and deflates both.  The shorter block may take at most 4 vectors per lane
+ * (an I x 512 matrix block: one), both blocks together at most 17; otherwise CMTFPLS_EUNSUPPORTED. */
 int cmtfpls_project_rows_f32(const float* X, int64_t I, int A, int B, int R, const double* WA, const double* WB,
                              const double* mean, double* scores, int ld, void* stream);
 int cmtfpls_project_rows_f64(const double* X, int64_t I, int A, int B, int R, const double* WA, const double* WB,
                              const double* mean, double* scores, int ld, void* stream);
+int cmtfpls_project_rows2_f32(const float* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
+                              const float* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,
+                              int64_t I, int R, double* scores, int ld, void* stream);
+int cmtfpls_project_rows2_f64(const double* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
+                              const double* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,
+                              int64_t I, int R, double* scores, int ld, void* stream);
 
 /* ---- collectives of the sharded loop for callers that drive this C ABI directly -----------------------
  * In-place all-reduce(sum) of a device buffer over the caller's RCCL communicator (an ncclComm_t passed as void*), on

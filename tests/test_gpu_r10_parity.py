@@ -77,12 +77,15 @@ def check(m, fit, title, blocks=(0,)):
         rows, extra = fit_error_table(m, fit, b)
         _record(f"{title} block {b}", rows, extra)
         err, fac, comp = worst(rows)
-        assert err <= RTOL, f"{title}: normwise error {err:.3e} > {RTOL:.0e} in {fac}[:, {comp}]"
-        assert max(extra["R2X_abs"]) <= RTOL and max(extra["R2Y_abs"]) <= RTOL
-        assert extra["coef_normwise"] <= 10 * RTOL
-        # iteration counts are part of parity: equal, or off by one where |du| crosses 1e-8 between
-        # two iterations within f32-storage rounding; a component that hits max_iter does so on both sides
-        assert all(abs(a - b) <= 1 for a, b in zip(extra["n_iter"], extra["n_iter_oracle"])), (extra["n_iter"], extra["n_iter_oracle"])
+        # the contract is 1e-5 (RTOL); measured on MI355X (profiles/r03b_r10_parity_table.txt): <= 1.6e-8 on every factor
+        # column of every configuration, so the guard sits at 1e-6 -- a regression of two orders fails here long before
+        # the contract is at risk
+        assert err <= RTOL / 10, f"{title}: normwise error {err:.3e} > {RTOL / 10:.0e} in {fac}[:, {comp}]"
+        assert max(extra["R2X_abs"]) <= RTOL / 10 and max(extra["R2Y_abs"]) <= RTOL / 10
+        assert extra["coef_normwise"] <= RTOL
+        # iteration counts are part of parity: EQUAL for every component of every configuration (f32
+        # storage, f64 accumulation: the convergence norm crosses 1e-8 at the same iteration as in the f64 oracle)
+        assert extra["n_iter"] == extra["n_iter_oracle"], (extra["n_iter"], extra["n_iter_oracle"])
 
 
 # ---- BASELINE configs[1] replica ------------------------------------------------------------------------

@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""transform / predict of samples WITH missing values at BASELINE configs[3] (65536 x 128 x 128 f32, 30 % NaN):
-the row-in-registers form (cmtfpls_project_rows_*: one read of the raw X) against the passes it replaces
-(clone + centre + R x fused score_deflate)."""
+"""transform / predict of samples WITH missing values: the row-in-registers form (cmtfpls_project_rows_* /
+cmtfpls_project_rows2_*: ONE read of the raw blocks, nothing written) against the passes it replaces (clone + centre +
+R x score / average / deflate), at
+  BASELINE configs[3]        65536 x 128 x 128 f32, 30 % NaN           (256-thread workgroups, 16 vectors per lane)
+  BASELINE configs[4]-shaped 32768 x 256 x 256 f32, 30 % NaN           (1024-thread workgroups, round 3)
+  BASELINE configs[2]        65536 x 128 x 128 + 65536 x 512, coupled  (both rows of a sample in one workgroup, round 3)
+Usage: python tools/nan_transform_time.py [cfg3|cfg5|coupled ...]"""
 import os, sys, time
+import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cmtf_pls_amd import tPLS
+from cmtf_pls_amd import ctPLS, tPLS
 from cmtf_pls_amd.synthetic import synthetic_shard_device
 from cmtf_pls_amd.tpls import to_device_copy
 
@@ -18,17 +23,38 @@ def clock(fn, n=3):
     return (time.perf_counter() - t0) / n, out
 
 
-X, Y = synthetic_shard_device((65536, 128, 128), 16, 10, error=0.1, device="cuda:0", nan_fraction=0.3, seed=217)
-m = tPLS(10, dtype="float32", algorithm="xcov")
-m.fit(X, Y, max_iter=30)
-eng = m._get_engine()
-t_new, s_new = clock(lambda: m.transform(X))
-t_ro, _ = clock(lambda: eng.project_readonly(m._state, [X]))
-t_old, s_old = clock(lambda: eng.project(m._state, [to_device_copy(X, torch.float32, "cuda:0")]).cpu().numpy())
-import numpy as np
-d = np.nanmax(np.abs(s_new - s_old)) / np.nanmax(np.abs(s_old))
-print(f"transform of 65536 x 128 x 128 f32 with 30 % NaN, R = 10: API {t_new*1e3:.2f} ms (engine.project_readonly {t_ro*1e3:.2f} ms: "
-      f"MTTKRP attempt + NaN flag + row-in-registers kernel) | clone + centre + 10 score_deflate passes {t_old*1e3:.2f} ms | "
-      f"max |diff| / max|scores| = {d:.1e}")
-t_p, _ = clock(lambda: m.predict(X))
-print(f"predict: {t_p*1e3:.2f} ms")
+def report(name, m, Xs, gbytes):
+    eng = m._get_engine()
+    arg = Xs if isinstance(m, ctPLS) else Xs[0]
+    t_new, s_new = clock(lambda: m.transform(arg))
+    t_ro, s_ro = clock(lambda: eng.project_readonly(m._state, Xs))
+    assert s_ro is not None, "the one-read form declined this shape"
+    t_old, s_old = clock(lambda: eng.project(m._state, [to_device_copy(X, torch.float32, "cuda:0") for X in Xs]).cpu().numpy())
+    d = np.nanmax(np.abs(s_new - s_old)) / np.nanmax(np.abs(s_old))
+    print(f"{name}: transform API {t_new*1e3:.2f} ms (engine.project_readonly {t_ro*1e3:.2f} ms = MTTKRP attempt + NaN flag + "
+          f"row-in-registers kernel, {gbytes / t_ro / 1e3:.2f} TB/s of X) | clone + centre + 10 passes {t_old*1e3:.2f} ms | "
+          f"max |diff| / max|scores| = {d:.1e}", flush=True)
+    t_p, _ = clock(lambda: m.predict(arg))
+    print(f"{name}: predict {t_p*1e3:.2f} ms", flush=True)
+
+
+which = sys.argv[1:] or ["cfg3", "cfg5", "coupled"]
+if "cfg3" in which:
+    X, Y = synthetic_shard_device((65536, 128, 128), 16, 10, error=0.1, device="cuda:0", nan_fraction=0.3, seed=217)
+    m = tPLS(10, dtype="float32", algorithm="xcov")
+    m.fit(X, Y, max_iter=30)
+    report("65536 x 128 x 128 f32, 30 % NaN, R = 10", m, [X], X.numel() * 4 / 1e9)
+    del X, Y, m
+if "cfg5" in which:
+    X, Y = synthetic_shard_device((32768, 256, 256), 32, 10, error=0.1, device="cuda:0", nan_fraction=0.3, seed=217)
+    m = tPLS(10, dtype="float32", algorithm="xcov")
+    m.fit(X, Y, max_iter=30)
+    report("32768 x 256 x 256 f32, 30 % NaN, R = 10", m, [X], X.numel() * 4 / 1e9)
+    del X, Y, m
+if "coupled" in which:
+    X, Y, Xm = synthetic_shard_device((65536, 128, 128), 16, 10, error=0.1, device="cuda:0", matrix_block=512, nan_fraction=0.3, seed=217)
+    from cmtf_pls_amd.backend import HipBackend
+    HipBackend(torch.device("cuda:0")).add_noise(Xm, 0.0, 991, 0, 0.3)          # the matrix block gets its own 30 % NaN mask
+    m = ctPLS(10, dtype="float32", algorithm="xcov")
+    m.fit([X, Xm], Y, max_iter=30)
+    report("65536 x 128 x 128 + 65536 x 512 f32 coupled, 30 % NaN, R = 10", m, [X, Xm], (X.numel() + Xm.numel()) * 4 / 1e9)
