@@ -488,8 +488,8 @@ def main():
             by_size.setdefault(nb, []).append(e0.elapsed_time(e1))
         comm_info = {"backend": backend, "ranks": dist.get_world_size(), "forced_single_rank": force_dist,
                      "allreduce_ms_by_bytes": {str(nb): sum(v) / len(v) for nb, v in sorted(by_size.items())},
-                     "allreduce_ms_per_step": sum(sum(v) for v in by_size.values()) / max(args.steps, 1),
-                     "collectives_per_step": len(comm.pairs) / max(args.steps, 1)}
+                     "allreduce_ms_per_step": sum(sum(v) for v in by_size.values()) / max(args.steps * reps, 1),
+                     "collectives_per_step": len(comm.pairs) / max(args.steps * reps, 1)}
     del Xw, Yw, run
 
     # ---- sec-to-fit leg (default tol / max_iter, like the reference's fit()) ----------------

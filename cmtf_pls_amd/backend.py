@@ -412,6 +412,35 @@ class HipBackend:
             _lib.check(rc, "loo_tpls")
         return Ypred, n_iter
 
+    def fit_small(self, X2: torch.Tensor, Y: torch.Tensor, A: int, B: int, R: int, tol: float, max_iter: int):
+        """The complete tPLS.fit of a small float64 problem without missing values in ONE launch (cmtfpls_fit_small_f64):
+        returns a dict of device tensors (T, U, WA, WB, Q, x_mean, y_mean) and host arrays (coef, ssq, n_iter), or None
+        when the shape is outside the one-workgroup form or the input holds a non-finite value (nothing usable written)."""
+        I, P = X2.shape
+        M = Y.shape[1]
+        if X2.dtype != torch.float64 or Y.dtype != torch.float64 or not (X2.is_contiguous() and Y.is_contiguous()) or I >= 2 ** 31 or P != A * B:
+            return None
+        nbytes = self.lib.cmtfpls_fit_small_workspace_bytes(I, A, B, M)
+        T, U = self.empty(I, R), self.empty(I, R)
+        WA, WB, Q = self.empty(A, R), self.empty(B, R), self.empty(M, R)
+        small = self.empty(R * R + 2 * (R + 1))                      # coef | ssq: one device -> host copy
+        xm, ym = self.empty(P), self.empty(M)
+        ints = torch.zeros(R + 1, dtype=torch.int32, device=self.device)    # n_iter | flag
+        # shape check first (no workspace is sized for a shape the kernel refuses)
+        ws = self._workspace("fit_small", max(nbytes, 256))
+        rc = self.lib.cmtfpls_fit_small_f64(_ptr(X2), _ptr(Y), I, A, B, M, R, float(tol), int(max_iter), _ptr(T), _ptr(U), _ptr(WA), _ptr(WB),
+                                            _ptr(Q), _ptr(small), small[R * R:].data_ptr(), _ptr(xm), _ptr(ym), _ptr(ints),
+                                            ints[R:].data_ptr(), _ptr(ws), ws.numel(), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "fit_small")
+        ih = ints.cpu().numpy()
+        if ih[R] != 0:
+            return None                                              # a NaN / inf somewhere: the regular (masked) engine takes it
+        sh = small.cpu().numpy()
+        return {"T": T, "U": U, "WA": WA, "WB": WB, "Q": Q, "x_mean": xm, "y_mean": ym, "coef": sh[:R * R].reshape(R, R).copy(),
+                "ssq": sh[R * R:].reshape(R + 1, 2).copy(), "n_iter": [int(v) for v in ih[:R]]}
+
     def add_noise(self, X: torch.Tensor, sigma: float, seed: int, offset: int = 0, nan_fraction: float = 0.0) -> torch.Tensor:
         """X += sigma * N(0,1) in place from the counter-based generator (element e of X is global element offset + e
         of the stream keyed by seed), then an i.i.d. NaN mask of density nan_fraction (synthetic.py:71,74)."""

@@ -19,7 +19,6 @@
 
 namespace cmtfpls {
 
-constexpr int kLooThreads = 256;
 constexpr int kLooMaxN = 64, kLooMaxR = 16, kLooMaxM = 64;
 
 struct LooArgs {
@@ -33,24 +32,41 @@ struct LooArgs {
   int64_t ws_per_fold;    // doubles
   int I, A, B, M, R, max_iter, fold0, nfolds;
   double tol;
+  // whole != 0 (round 3, cmtfpls_fit_small_f64): ONE workgroup fits ALL I samples -- no held-out row, means over I rows
+  // formed here -- and writes the fitted state instead of a prediction: the complete tPLS.fit (tpls.py:73-120) of a small
+  // problem in one launch.  T goes to ws (I x R, the caller's output buffer).
+  int whole;
+  double* U_out;          // (I, R)  Y scores
+  double* WA_out;         // (A, R)
+  double* WB_out;         // (B, R)
+  double* Q_out;          // (M, R)
+  double* coef_out;       // (R, R)
+  double* ssq_out;        // (R + 1, 2): row 0 = |X_c|^2, |Y_c|^2; row a + 1 = the same after deflating component a
+  double* xmean_out;      // (P)
+  double* ymean_out;      // (M)
+  int* flag_out;          // set to 1 when X or Y holds a non-finite value (the caller then takes the regular engine)
+  double* T_whole;        // (I, R) X scores (whole fit)
 };
 
 // sum over the workgroup; every thread gets the same value; two barriers, so back-to-back calls may share `red`
+template <int NT>
 __device__ __forceinline__ double loo_sum(double v, double* red) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = 0.0;
 #pragma unroll
-  for (int w = 0; w < kLooThreads / 64; ++w) s += red[w];
+  for (int w = 0; w < NT / 64; ++w) s += red[w];
   __syncthreads();
   return s;
 }
 
 // Leading singular pair of Z (A x B row-major in LDS): wA (A), wB (B) unit norm, largest-|.| entry of wB positive.
 // G0/G1: n*n doubles each; xs: n; ys: k (n = min(A,B), k = max(A,B)).  All threads must call it.
+template <int NT>
 __device__ void loo_rank1(const double* Z, int A, int B, double* wA, double* wB, double* G0, double* G1, double* xs, double* ys,
                           double* red, int* ired) {
+  constexpr int kLooThreads = NT;
   const int tid = threadIdx.x;
   const bool rowsA = A <= B;                        // M = Z (n = A) or Z^T (n = B)
   const int n = rowsA ? A : B, k = rowsA ? B : A;
@@ -71,7 +87,7 @@ __device__ void loo_rank1(const double* Z, int A, int B, double* wA, double* wB,
       frp = fma(g, g, frp);
       if (o / n == o % n) trp += g;
     }
-    const double tr = loo_sum(trp, red), fro = loo_sum(frp, red);
+    const double tr = loo_sum<NT>(trp, red), fro = loo_sum<NT>(frp, red);
     if (!(tr > 0.0) || !isfinite(tr) || fro / (tr * tr) >= 1.0 - 1e-13) break;      // uniform
     int e;
     frexp(tr, &e);
@@ -96,7 +112,7 @@ __device__ void loo_rank1(const double* Z, int A, int B, double* wA, double* wB,
   const int bi = ired[0];
   double ss = 0.0;
   for (int i = tid; i < n; i += kLooThreads) { const double g = G[bi * n + i]; ss = fma(g, g, ss); }
-  const double snrm = sqrt(loo_sum(ss, red));
+  const double snrm = sqrt(loo_sum<NT>(ss, red));
   for (int i = tid; i < n; i += kLooThreads) xs[i] = G[bi * n + i] / snrm;          // xs = seed for now
   __syncthreads();
   for (int l = tid; l < k; l += kLooThreads) {                                       // y = M^T seed
@@ -114,7 +130,7 @@ __device__ void loo_rank1(const double* Z, int A, int B, double* wA, double* wB,
   double sx = 0.0, sy = 0.0;
   for (int i = tid; i < n; i += kLooThreads) sx = fma(xs[i], xs[i], sx);
   for (int l = tid; l < k; l += kLooThreads) sy = fma(ys[l], ys[l], sy);
-  const double nx = sqrt(loo_sum(sx, red)), ny = sqrt(loo_sum(sy, red));
+  const double nx = sqrt(loo_sum<NT>(sx, red)), ny = sqrt(loo_sum<NT>(sy, red));
   // sign rule on the LAST mode's vector wB: its largest-|.| entry is positive (first index on ties)
   const double* vb = rowsA ? ys : xs;
   const int nb = rowsA ? k : n;
@@ -133,18 +149,23 @@ __device__ void loo_rank1(const double* Z, int A, int B, double* wA, double* wB,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
+// NT = 256 for the leave-one-out launch (one workgroup per fold, the folds side by side on the CUs); NT = 1024 for the
+// whole fit, where the one workgroup is all the parallelism there is
+template <int NT>
+__global__ __launch_bounds__(NT) void loo_tpls_kernel(LooArgs a) {
+  constexpr int kLooThreads = NT;
   extern __shared__ double sm[];
-  __shared__ double red[8];
+  __shared__ double red[16];
   __shared__ int ired[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int I = a.I, A = a.A, B = a.B, M = a.M, R = a.R, P = A * B;
   const int n = A < B ? A : B, k = A < B ? B : A;
-  const int fold = a.fold0 + blockIdx.x;
-  if (blockIdx.x >= a.nfolds || fold >= I) return;
+  const bool whole = a.whole != 0;
+  const int fold = whole ? -1 : a.fold0 + blockIdx.x;              // -1: no row is held out
+  if (!whole && (blockIdx.x >= a.nfolds || fold >= I)) return;
   double* Xf = a.ws + (int64_t)blockIdx.x * a.ws_per_fold;
   double* Yf = Xf + (int64_t)I * P;
-  double* T = Yf + (int64_t)I * M;
+  double* T = whole ? a.T_whole : Yf + (int64_t)I * M;
   // LDS carve-up
   double* u = sm;
   double* t = u + I;
@@ -166,16 +187,38 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
   double* gn = Gn + R * R;
   double* bb = gn + R;
   double* dd = bb + R;
-  const double inv = 1.0 / (double)(I - 1);
+  double* part = dd + R;          // NT doubles: partial rows of the contraction when P < NT
+  const int nrg = (P < kLooThreads) ? kLooThreads / P : 1;
+  const double inv = 1.0 / (double)(whole ? I : I - 1);
 
   // ---- preprocess (tpls.py:61-71): means over the I - 1 training rows by down-dating the column sums; the
-  // held-out row is zero in the working copies, i.e. absent from every sum below
-  for (int m = tid; m < M; m += kLooThreads) my[m] = (a.colsum_y[m] - a.Y[(int64_t)fold * M + m]) * inv;
+  // held-out row is zero in the working copies, i.e. absent from every sum below.  (whole fit: the column sums are
+  // formed here, over all I rows; a non-finite sum = a missing value somewhere: flag it and leave)
   for (int o = tid; o < R * R; o += kLooThreads) coef[o] = 0.0;
-  __syncthreads();
-  for (int c = tid; c < P; c += kLooThreads) {
-    const double mu = (a.colsum_x[c] - a.X[(int64_t)fold * P + c]) * inv;
-    Z[c] = mu;                                            // kept in Z until the first iteration overwrites it
+  if (whole) {
+    double bad = 0.0;
+    for (int m = tid; m < M; m += kLooThreads) {
+      double s = 0.0;
+      for (int r = 0; r < I; ++r) s += a.Y[(int64_t)r * M + m];
+      my[m] = s / (double)I;                                            // nanmean without NaNs (tpls.py:67)
+      if (!isfinite(s)) bad = 1.0;
+    }
+    for (int c = tid; c < P; c += kLooThreads) {
+      double s = 0.0;
+      for (int r = 0; r < I; ++r) s += a.X[(int64_t)r * P + c];
+      Z[c] = s / (double)I;                                             // tpls.py:66
+      if (!isfinite(s)) bad = 1.0;
+    }
+    bad = loo_sum<NT>(bad, red);
+    if (bad > 0.0) { if (tid == 0) *a.flag_out = 1; return; }           // uniform
+    for (int c = tid; c < P; c += kLooThreads) a.xmean_out[c] = Z[c];
+    for (int m = tid; m < M; m += kLooThreads) a.ymean_out[m] = my[m];
+  } else {
+    for (int m = tid; m < M; m += kLooThreads) my[m] = (a.colsum_y[m] - a.Y[(int64_t)fold * M + m]) * inv;
+    for (int c = tid; c < P; c += kLooThreads) {
+      const double mu = (a.colsum_x[c] - a.X[(int64_t)fold * P + c]) * inv;
+      Z[c] = mu;                                            // kept in Z until the first iteration overwrites it
+    }
   }
   __syncthreads();
   for (int64_t idx = tid; idx < (int64_t)I * P; idx += kLooThreads) {
@@ -187,6 +230,14 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
     Yf[idx] = (r == fold) ? 0.0 : a.Y[idx] - my[m];
   }
   __syncthreads();
+  if (whole) {                                                           // |X_c|^2, |Y_c|^2: the R2X / R2Y denominators
+    double sx = 0.0, sy = 0.0;
+    for (int64_t idx = tid; idx < (int64_t)I * P; idx += kLooThreads) sx = fma(Xf[idx], Xf[idx], sx);
+    for (int64_t idx = tid; idx < (int64_t)I * M; idx += kLooThreads) sy = fma(Yf[idx], Yf[idx], sy);
+    sx = loo_sum<NT>(sx, red);
+    sy = loo_sum<NT>(sy, red);
+    if (tid == 0) { a.ssq_out[0] = sx; a.ssq_out[1] = sy; }
+  }
 
   for (int comp = 0; comp < R; ++comp) {
     for (int r = tid; r < I; r += kLooThreads) u[r] = Yf[(int64_t)r * M];             // tpls.py:78
@@ -194,21 +245,37 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
     int it = 0;
     for (; it < a.max_iter; ++it) {                                                    // tpls.py:79
       // Z = X x_0 u (tpls.py:83): a thread owns columns, rows stream past (coalesced across the workgroup)
-      for (int c = tid; c < P; c += kLooThreads) {
-        double s = 0.0;
-        for (int r = 0; r < I; ++r) s = fma(Xf[(int64_t)r * P + c], u[r], s);
-        Z[c] = s;
+      // (fewer columns than threads: nrg row groups share the rows of a column, partial rows added in index order)
+      if (nrg == 1) {
+        for (int c = tid; c < P; c += kLooThreads) {
+          double s = 0.0;
+          for (int r = 0; r < I; ++r) s = fma(Xf[(int64_t)r * P + c], u[r], s);
+          Z[c] = s;
+        }
+      } else {
+        const int rg = tid / P, c = tid % P;
+        if (rg < nrg) {
+          double s = 0.0;
+          for (int r = rg; r < I; r += nrg) s = fma(Xf[(int64_t)r * P + c], u[r], s);
+          part[rg * P + c] = s;
+        }
+        __syncthreads();
+        for (int c2 = tid; c2 < P; c2 += kLooThreads) {
+          double s = 0.0;
+          for (int g = 0; g < nrg; ++g) s += part[g * P + c2];
+          Z[c2] = s;
+        }
       }
       __syncthreads();
       if (A == 1) {                                                                    // tpls.py:84: Z / norm(Z)
         double s = 0.0;
         for (int c = tid; c < P; c += kLooThreads) s = fma(Z[c], Z[c], s);
-        const double nz = sqrt(loo_sum(s, red));
+        const double nz = sqrt(loo_sum<NT>(s, red));
         for (int c = tid; c < P; c += kLooThreads) wB[c] = Z[c] / nz;
         if (tid == 0) wA[0] = 1.0;
         __syncthreads();
       } else {
-        loo_rank1(Z, A, B, wA, wB, G0, G1, xs, ys, red, ired);                         // tpls.py:86-88
+        loo_rank1<NT>(Z, A, B, wA, wB, G0, G1, xs, ys, red, ired);                         // tpls.py:86-88
       }
       // t = X x_1 wA x_2 wB (tpls.py:97-99): one wavefront per row
       for (int r = wv; r < I; r += kLooThreads / 64) {
@@ -226,7 +293,7 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
       }
       __syncthreads();
       double qs = (tid < M) ? q[tid] * q[tid] : 0.0;
-      const double qnrm = sqrt(loo_sum(qs, red));
+      const double qnrm = sqrt(loo_sum<NT>(qs, red));
       if (tid < M) qn[tid] = q[tid] / qnrm;
       __syncthreads();
       // u = Y q and |u_old - u| (tpls.py:102-103)
@@ -238,18 +305,26 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
         du2 = fma(d0, d0, du2);
         u[r] = s;
       }
-      const double du = sqrt(loo_sum(du2, red));
+      const double du = sqrt(loo_sum<NT>(du2, red));
       if (it > 0 && du < a.tol) { ++it; break; }                                       // first pass: oldU = inf (tpls.py:77)
     }
-    if (a.n_iter && tid == 0) a.n_iter[(int64_t)fold * R + comp] = it;
+    if (a.n_iter && tid == 0) a.n_iter[(int64_t)(whole ? 0 : fold) * R + comp] = it;
     // store the component; deflate X (tpls.py:109)
     for (int r = tid; r < I; r += kLooThreads) T[(int64_t)r * R + comp] = t[r];
     for (int j = tid; j < A; j += kLooThreads) Wa[comp * A + j] = wA[j];
     for (int j = tid; j < B; j += kLooThreads) Wb[comp * B + j] = wB[j];
     for (int m = tid; m < M; m += kLooThreads) Qs[comp * M + m] = qn[m];
+    double ssx = 0.0;
     for (int64_t idx = tid; idx < (int64_t)I * P; idx += kLooThreads) {
       const int r = (int)(idx / P), c = (int)(idx % P);
-      Xf[idx] -= t[r] * (wA[c / B] * wB[c % B]);
+      const double v = Xf[idx] - t[r] * (wA[c / B] * wB[c % B]);
+      Xf[idx] = v;
+      ssx = fma(v, v, ssx);
+    }
+    if (whole) {
+      for (int r = tid; r < I; r += kLooThreads) a.U_out[(int64_t)r * R + comp] = u[r];
+      ssx = loo_sum<NT>(ssx, red);                                           // R2X[comp] = 1 - |X_{comp+1}|^2 / |X_c|^2 (tpls.py:115-117)
+      if (tid == 0) a.ssq_out[2 * (comp + 1)] = ssx;
     }
     __syncthreads();
     // inner regression b = lstsq(T[:, :k], u) (tpls.py:110-112): normal equations, equilibrated Cholesky
@@ -305,11 +380,25 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
       t[r] = s;
     }
     __syncthreads();
+    double ssy = 0.0;
     for (int64_t idx = tid; idx < (int64_t)I * M; idx += kLooThreads) {
       const int r = (int)(idx / M), m = (int)(idx % M);
-      Yf[idx] -= t[r] * qn[m];
+      const double v = Yf[idx] - t[r] * qn[m];
+      Yf[idx] = v;
+      ssy = fma(v, v, ssy);
+    }
+    if (whole) {
+      ssy = loo_sum<NT>(ssy, red);                                           // R2Y[comp] = 1 - |Y_{comp+1}|^2 / |Y_c|^2 (tpls.py:118-120)
+      if (tid == 0) a.ssq_out[2 * (comp + 1) + 1] = ssy;
     }
     __syncthreads();
+  }
+  if (whole) {                                                           // the fitted state (T is already in the caller's buffer)
+    for (int o = tid; o < R * A; o += kLooThreads) a.WA_out[(int64_t)(o % A) * R + o / A] = Wa[o];
+    for (int o = tid; o < R * B; o += kLooThreads) a.WB_out[(int64_t)(o % B) * R + o / B] = Wb[o];
+    for (int o = tid; o < R * M; o += kLooThreads) a.Q_out[(int64_t)(o % M) * R + o / M] = Qs[o];
+    for (int o = tid; o < R * R; o += kLooThreads) a.coef_out[o] = coef[o];
+    return;
   }
 
   // ---- predict the held-out sample (tpls.py:122-143): centre with the fold's means, project and deflate
@@ -319,7 +408,7 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
   for (int comp = 0; comp < R; ++comp) {
     double s = 0.0;
     for (int c = tid; c < P; c += kLooThreads) s = fma(Z[c], Wa[comp * A + c / B] * Wb[comp * B + c % B], s);
-    const double sv = loo_sum(s, red);
+    const double sv = loo_sum<NT>(s, red);
     if (tid == 0) sc[comp] = sv;
     for (int c = tid; c < P; c += kLooThreads) Z[c] -= sv * (Wa[comp * A + c / B] * Wb[comp * B + c % B]);
     __syncthreads();
@@ -335,10 +424,10 @@ __global__ __launch_bounds__(kLooThreads) void loo_tpls_kernel(LooArgs a) {
   }
 }
 
-static size_t loo_lds_bytes(int I, int A, int B, int M, int R) {
+static size_t loo_lds_bytes(int I, int A, int B, int M, int R, int NT) {
   const size_t n = (size_t)(A < B ? A : B), k = (size_t)(A < B ? B : A), P = (size_t)A * B;
   const size_t dbl = 2 * (size_t)I + P + A + B + 2 * (size_t)M + 2 * n * n + n + k + M + (size_t)R * R + (size_t)R * (A + B) +
-                     (size_t)R * M + (size_t)R * R + 3 * (size_t)R;
+                     (size_t)R * M + (size_t)R * R + 3 * (size_t)R + (size_t)NT;
   return dbl * sizeof(double);
 }
 
@@ -362,7 +451,7 @@ int cmtfpls_loo_tpls_f64(const double* X, const double* Y, const double* colsum_
     return CMTFPLS_EINVAL;
   }
   const int n = A < B ? A : B;
-  const size_t lds = loo_lds_bytes(I, A, B, M, R);
+  const size_t lds = loo_lds_bytes(I, A, B, M, R, 256);
   if (n > kLooMaxN || M > kLooMaxM || R > kLooMaxR || lds > 150 * 1024) {
     set_error("loo_tpls: shape outside the one-workgroup-per-fold form; refit per fold on the regular engine");
     return CMTFPLS_EUNSUPPORTED;
@@ -373,9 +462,47 @@ int cmtfpls_loo_tpls_f64(const double* X, const double* Y, const double* colsum_
   a.X = X; a.Y = Y; a.colsum_x = colsum_x; a.colsum_y = colsum_y; a.ws = static_cast<double*>(ws); a.Ypred = Ypred; a.n_iter = n_iter;
   a.ws_per_fold = (int64_t)(per / sizeof(double));
   a.I = I; a.A = A; a.B = B; a.M = M; a.R = R; a.max_iter = max_iter; a.fold0 = fold0; a.nfolds = nfolds; a.tol = tol;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(loo_tpls_kernel, dim3(nfolds), dim3(kLooThreads), lds, (hipStream_t)stream, a);
+  a.whole = 0;
+  a.T_whole = nullptr;
+  a.U_out = a.WA_out = a.WB_out = a.Q_out = a.coef_out = a.ssq_out = a.xmean_out = a.ymean_out = nullptr;
+  a.flag_out = nullptr;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(loo_tpls_kernel<256>, dim3(nfolds), dim3(256), lds, (hipStream_t)stream, a);
   return check_launch("loo_tpls");
+}
+
+size_t cmtfpls_fit_small_workspace_bytes(int I, int A, int B, int M) {
+  if (I <= 1 || A <= 0 || B <= 0 || M <= 0) return 0;
+  return ((size_t)I * A * B + (size_t)I * M) * sizeof(double);
+}
+
+int cmtfpls_fit_small_f64(const double* X, const double* Y, int I, int A, int B, int M, int R, double tol, int max_iter,
+                          double* T, double* U, double* WA, double* WB, double* Q, double* coef, double* ssq, double* x_mean,
+                          double* y_mean, int* n_iter, int* flag, void* ws, size_t ws_bytes, void* stream) {
+  if (!X || !Y || !T || !U || !WA || !WB || !Q || !coef || !ssq || !x_mean || !y_mean || !n_iter || !flag || I <= 1 || A <= 0 || B <= 0 ||
+      M <= 0 || R <= 0 || max_iter <= 0) {
+    set_error("fit_small: bad argument");
+    return CMTFPLS_EINVAL;
+  }
+  const int n = A < B ? A : B;
+  const size_t lds = loo_lds_bytes(I, A, B, M, R, 1024);
+  if (n > kLooMaxN || M > kLooMaxM || R > kLooMaxR || lds > 150 * 1024) {
+    set_error("fit_small: shape outside the one-workgroup form; use the regular engine");
+    return CMTFPLS_EUNSUPPORTED;
+  }
+  if (!ws || ws_bytes < cmtfpls_fit_small_workspace_bytes(I, A, B, M)) { set_error("fit_small: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  // workspace: Xf (I * P) | Yf (I * M); the kernel's third slot (T, I x R) is the caller's output buffer
+  LooArgs a;
+  a.X = X; a.Y = Y; a.colsum_x = nullptr; a.colsum_y = nullptr; a.ws = static_cast<double*>(ws); a.Ypred = nullptr; a.n_iter = n_iter;
+  a.ws_per_fold = 0;
+  a.I = I; a.A = A; a.B = B; a.M = M; a.R = R; a.max_iter = max_iter; a.fold0 = 0; a.nfolds = 1; a.tol = tol;
+  a.whole = 1;
+  a.T_whole = T;
+  a.U_out = U; a.WA_out = WA; a.WB_out = WB; a.Q_out = Q; a.coef_out = coef; a.ssq_out = ssq; a.xmean_out = x_mean; a.ymean_out = y_mean;
+  a.flag_out = flag;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(loo_tpls_kernel<1024>, dim3(1), dim3(1024), lds, (hipStream_t)stream, a);
+  return check_launch("fit_small");
 }
 
 }  // extern "C"

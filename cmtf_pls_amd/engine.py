@@ -206,6 +206,9 @@ class NipalsEngine:
         algorithm: "direct" = the reference's loop (two X reads per iteration); "xcov" = the same
         iteration re-associated through S = X_(0)^T Y (one X read + one read/write per component)."""
         with self.device_ctx():
+            small = self._fit_small(Xs, Y, n_components, tol, max_iter, coupled, verbose, on_preprocessed)
+            if small is not None:
+                return small
             run = self.begin(Xs, Y, n_components, coupled, algorithm)
             if on_preprocessed is not None:                          # the estimators print their missing-value notice
                 on_preprocessed(run.blocks)                          # here, where the reference does (tpls.py:62-63)
@@ -222,6 +225,38 @@ class NipalsEngine:
                         break
                 run.finish_component(a)
             return run.result()
+
+    # fits below this many elements of X go through ONE launch when the shape allows it: a regular iteration is ~20
+    # launches of pure latency whatever the size, a one-workgroup iteration costs time in proportion to I * P
+    small_fit_elements = 1 << 15    # measured (profiles/r03d_small_fit.txt): 2.2x faster at 16000 elements, slower from 65536 on
+    small_fit = True
+
+    def _fit_small(self, Xs, Y, n_components, tol, max_iter, coupled, verbose, on_preprocessed) -> Optional[FitState]:
+        """The whole fit in ONE launch of one workgroup (cmtfpls_fit_small_f64) for a single small float64 block of order
+        2 or 3 without missing values, unsharded (BASELINE configs[0]); None when it does not apply -- the caller then
+        runs the regular loop.  Same operations in the reference's order (tpls.py:73-120); sums are formed in a different
+        order than the multi-launch kernels form them, i.e. results agree to rounding."""
+        be = self.be
+        if not (self.small_fit and hasattr(be, "fit_small")) or len(Xs) != 1 or self.comm.sharded or verbose:
+            return None
+        X = Xs[0]
+        if X.dtype != torch.float64 or X.dim() not in (2, 3) or X.numel() > self.small_fit_elements or X.shape[0] < 2:
+            return None
+        validate_limits([tuple(X.shape)], n_components)
+        I = X.shape[0]
+        A, B = split_trailing(X.shape)
+        out = be.fit_small(X.view(I, -1), Y, A, B, n_components, tol, max_iter)
+        if out is None:
+            return None
+        R = n_components
+        ssq = out["ssq"]
+        loadings = [out["WB"]] if X.dim() == 2 else [out["WA"], out["WB"]]
+        blk = BlockState(shape=tuple(X.shape), A=A, B=B, mean=out["x_mean"], has_miss=False, colcnt=None, rowcnt=None,
+                         ssq0=float(ssq[0, 0]), dtype=X.dtype, loadings=loadings, r2x=1.0 - ssq[1:, 0] / ssq[0, 0])
+        if on_preprocessed is not None:
+            on_preprocessed([blk])
+        return FitState(coupled=coupled, n_components=R, blocks=[blk], T=out["T"], U=out["U"], Q=out["Q"], coef=out["coef"],
+                        r2y=1.0 - ssq[1:, 1] / ssq[0, 1], y_mean=out["y_mean"], n_iter=out["n_iter"], n_samples_total=I)
 
     # ------------------------------------------------------------------------------------
     def project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool = True, mixed: bool = False) -> torch.Tensor:

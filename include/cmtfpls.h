@@ -329,6 +329,19 @@ size_t cmtfpls_loo_fold_workspace_bytes(int I, int A, int B, int M, int R);
 int cmtfpls_loo_tpls_f64(const double* X, const double* Y, const double* colsum_x, const double* colsum_y, int I, int A,
                          int B, int M, int R, double tol, int max_iter, int fold0, int nfolds, double* Ypred,
                          int* n_iter, void* ws, size_t ws_bytes, void* stream);
+/* fit_small: the COMPLETE tPLS.fit (tpls.py:73-120: preprocess, every component's NIPALS loop with its convergence test,
+ * rank-1 extraction, deflation, inner regression, Y deflation) of a small problem in ONE launch of one workgroup -- a fit of
+ * BASELINE configs[0] (200 x 10 x 8, R = 3) is otherwise a few hundred launches of pure latency.  float64, X of order 2 or 3
+ * (A = 1 for a matrix) WITHOUT missing values; limits as loo_tpls: min(A, B) <= 64, M <= 64, R <= 16, the workgroup's vectors
+ * within 150 KB of LDS (CMTFPLS_EUNSUPPORTED otherwise).  Outputs (device): T (I x R), U (I x R), WA (A x R), WB (B x R),
+ * Q (M x R), coef (R x R), ssq ((R + 1) x 2: row 0 = |X_c|^2, |Y_c|^2, row a + 1 = the deflated norms after component a, so
+ * R2X[a] = 1 - ssq[a+1][0] / ssq[0][0] and R2Y likewise, tpls.py:115-120), x_mean (A * B), y_mean (M), n_iter (R ints),
+ * flag (one int, zeroed by the caller: set to 1, nothing else written, when X or Y holds a non-finite value).
+ * ws: cmtfpls_fit_small_workspace_bytes (the centred working copies of X and Y). */
+size_t cmtfpls_fit_small_workspace_bytes(int I, int A, int B, int M);
+int cmtfpls_fit_small_f64(const double* X, const double* Y, int I, int A, int B, int M, int R, double tol, int max_iter,
+                          double* T, double* U, double* WA, double* WB, double* Q, double* coef, double* ssq, double* x_mean,
+                          double* y_mean, int* n_iter, int* flag, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- synthetic inputs on the device: cmtf_pls/synthetic.py:59-74 (import_synthetic), :5-34 (make_synthetic_test)
  * The dense CP tensor of the drawn factors is cmtfpls_recon_* with T = the sample factor; add_noise then adds

@@ -11,7 +11,7 @@ import pytest
 from numpy.linalg import norm
 from numpy.testing import assert_allclose
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.small_fit]      # the product's default behaviour, small fits included
 
 TENSOR_DIMENSIONS = (100, 38, 65)      # tests/test_tpls.py:13-15, tests/test_synthetic.py:4-6
 N_RESPONSE = 4

@@ -246,3 +246,53 @@ def test_coupled_nan_transform_from_one_read(api, monkeypatch, dtype):
     p = m.predict([xt, xmt])
     wantp = O.predict(fit, [xt, xmt])
     assert _normwise(p[keep], wantp[keep]) <= 10 * tol
+
+
+# ---- the whole small fit in one launch (VERDICT r2 "Next" #8) ------------------------------------------------------------------
+@pytest.mark.small_fit
+@pytest.mark.parametrize("shape,M,R", [((200, 10, 8), 4, 3), ((120, 40), 3, 4), ((64, 7, 33), 1, 16), ((300, 12, 12), 16, 5)])
+def test_small_fit_in_one_launch_equals_the_regular_engine(api, monkeypatch, shape, M, R):
+    """BASELINE configs[0] and neighbours: tPLS.fit of a small float64 problem is ONE kernel launch (cmtfpls_fit_small_f64);
+    same iteration counts, factors equal to the multi-launch engine to 1e-12 and to the oracle."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    x, y, _ = O.import_synthetic(shape, M, min(R, 4), error=0.1, seed=7)
+    calls = _count_calls(monkeypatch, ["fit_small", "colstats", "mode0_contract", "mode0_contract_yq", "rank1"])
+    one = api.tPLS(R)
+    one.fit(x, y)
+    assert calls["fit_small"] == 1 and calls["colstats"] == calls["mode0_contract"] == calls["mode0_contract_yq"] == calls["rank1"] == 0
+    monkeypatch.setattr(NipalsEngine, "small_fit", False)
+    reg = api.tPLS(R)
+    reg.fit(x, y)
+    assert calls["fit_small"] == 1 and calls["colstats"] > 0
+    assert one.n_iter_ == reg.n_iter_
+    for f, g in zip(one.X_factors + one.Y_factors, reg.X_factors + reg.Y_factors):
+        assert f.shape == g.shape
+        assert _normwise(f, g) <= 1e-10          # (late components of a noise-free remainder amplify rounding; early ones: 1e-14)
+    assert _normwise(one.X_factors[0][:, :2], reg.X_factors[0][:, :2]) <= 1e-12
+    assert_allclose(one.R2X, reg.R2X, rtol=0, atol=1e-12)
+    assert_allclose(one.R2Y, reg.R2Y, rtol=0, atol=1e-12)
+    assert_allclose(one.coef_, reg.coef_, rtol=0, atol=1e-9 * np.abs(reg.coef_).max())
+    assert_allclose(one.X_mean, reg.X_mean, rtol=1e-13, atol=1e-15)
+    fit = O.fit_tpls(x, y, R)
+    assert one.n_iter_ == fit.n_iter
+    assert _normwise(one.X_factors[0][:, :3], fit.T[:, :3]) <= 1e-9
+    assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-10)
+    assert_allclose(one.transform(x), one.X_factors[0], rtol=1e-8, atol=1e-10)     # tests/test_tpls.py:145-155
+    assert_allclose(one.predict(x[:9]), O.predict(fit, x[:9]), rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.small_fit
+def test_small_fit_declines_missing_values_and_large_inputs(api, monkeypatch):
+    x, y, _ = O.import_synthetic((60, 9, 8), 3, 3, error=0.1, seed=8)
+    xn = x.copy()
+    xn[4, 2, 1] = np.nan
+    calls = _count_calls(monkeypatch, ["fit_small", "colstats"])
+    m = api.tPLS(2)
+    m.fit(xn, y)
+    assert calls["fit_small"] == 1 and calls["colstats"] > 0 and m.X_hasMiss          # flagged in the kernel, refitted by the masked engine
+    fit = O.fit_tpls(xn, y, 2)
+    assert _normwise(m.X_factors[0], fit.T) <= 1e-8
+    big, yb, _ = O.import_synthetic((80, 40, 40), 3, 3, error=0.1, seed=9)        # 128000 elements: beyond the one-workgroup budget
+    calls["fit_small"] = 0
+    api.tPLS(2).fit(big, yb)
+    assert calls["fit_small"] == 0
