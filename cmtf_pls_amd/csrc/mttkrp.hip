@@ -26,6 +26,8 @@
 // 16-wide tile that R = 10 components occupy cost ~47 ns each per SIMD at the clock the chip holds under f64 MFMA
 // load.  The LDS weight path adds 0.1 ms on top; sharing one B operand between two row groups recovers half of
 // that (0.82 ms) and was not worth a second kernel form.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace cmtfpls {
@@ -114,6 +116,128 @@ __global__ __launch_bounds__(NT) void mttkrp_kernel(const T* __restrict__ X, int
 }
 
 
+// ---- round 3: the "j-block" form -------------------------------------------------------------------------------------
+//   M[i, r] = sum_j WA[j, r] * ( sum_k X[i, j, k] * WB[k, r] )
+// One MFMA = 16 consecutive j-rows of ONE sample x 16 components x 4 k's:
+//   A operand  X[i][16 jb + (l & 15)][k]   (the lane's 16-byte vector holds V consecutive k's; element e feeds MFMA e)
+//   B operand  WB[k][r = l & 15]           -- a plain loading entry: NO product formed per MFMA (the round-2 form read two
+//                                             LDS words and multiplied them for every MFMA), held in REGISTERS for the whole
+//                                             kernel when the trailing extent allows (B / 4 doubles per lane), else one LDS read
+//   D[(l >> 4) + 4 g][l & 15] = sum_k X[i][16 jb + (l >> 4) + 4 g][k] WB[k][r]; at the end of a j-block the four accumulator
+//   entries are multiplied by WA[j][r] and added into ONE running double per lane; the four lane groups are summed by two
+//   butterfly steps at the end of the sample.
+// A wavefront owns whole samples (no partial rows, fixed summation order) and reads each as 16-row slabs of 16 * B contiguous
+// elements (8 KB at 128 x 128 f32) instead of 16 rows 64 KB apart; the next slab's loads are in flight while the current
+// one is on the matrix cores.  Shapes: A % 16 == 0, B a multiple of 4 V CH elements (V = 16 / sizeof(T)), R <= 16; anything
+// else keeps the tile form above.
+template <typename T, int CH, int NPJ, bool BREG>
+__global__ __launch_bounds__(256) void mttkrp_jk_kernel(const T* __restrict__ X, int64_t I, int A, int B,
+                                                        const double* __restrict__ WA, const double* __restrict__ WB, int R,
+                                                        double* __restrict__ out, int ldo) {
+  constexpr int V = VecOf<T>::N;
+  constexpr int RP = 16;
+#ifndef CMTFPLS_MTTKRP_NACC
+#define CMTFPLS_MTTKRP_NACC 1
+#endif
+  constexpr int NACC = CMTFPLS_MTTKRP_NACC;
+  extern __shared__ double lds[];          // sA[A][16] then sB[B][16], zero padded beyond R
+  double* sA = lds;
+  double* sB = lds + (size_t)A * RP;
+  for (int idx = threadIdx.x; idx < A * RP; idx += 256) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
+  for (int idx = threadIdx.x; idx < B * RP; idx += 256) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int jr = lane & 15, kq = lane >> 4;
+  const int64_t P = (int64_t)A * B;
+  const int njb = A / 16;
+  const int npj = BREG ? NPJ : B / (4 * V * CH);      // chunks of CH patches per j-block
+  using XV = Pack<T, V>;
+  double breg[BREG ? NPJ * CH : 1][V];
+  if (BREG) {
+#pragma unroll
+    for (int p = 0; p < NPJ * CH; ++p)
+#pragma unroll
+      for (int e = 0; e < V; ++e) breg[p][e] = sB[(size_t)(p * 4 * V + V * kq + e) * RP + jr];
+  }
+  const int nchunks = njb * npj, npairs = nchunks / 2;
+  const int64_t istep = (int64_t)gridDim.x * 4;
+  // Two register buffers in fixed roles (chunks q even / q odd): no buffer is ever copied and no load sits behind a
+  // branch, so the wait in front of a chunk's MFMAs covers its own CH loads only (vmcnt(CH)) and the other buffer's CH
+  // loads stay in flight behind them.  (A first form that copied `next` into `current`, and a second one that guarded the
+  // prefetches with `if (q + 1 < nchunks)`, both made the compiler wait for ALL loads in front of the MFMAs.)  The last
+  // prefetch of a sample fetches the first chunk of the wavefront's NEXT sample (its own again when there is none).
+  XV b0[CH], b1[CH];
+  auto load = [&](XV (&buf)[CH], const T* __restrict__ xs, int q) {
+    const int jb = BREG ? q / NPJ : q / npj, c = BREG ? q % NPJ : q - jb * npj;
+    const T* __restrict__ xp = xs + (int64_t)jb * 16 * B + c * CH * 4 * V;
+#pragma unroll
+    for (int p = 0; p < CH; ++p) buf[p] = ld_stream(reinterpret_cast<const XV*>(xp + p * 4 * V));
+  };
+  int64_t i = (int64_t)blockIdx.x * 4 + wv;
+  // the lane's corner of every chunk: row jr of the j-block, columns V kq .. V kq + V - 1 of the patch
+  const int64_t lane_off = (int64_t)jr * B + V * kq;
+  if (i < I) load(b0, X + i * P + lane_off, 0);
+  for (; i < I; i += istep) {
+    const T* __restrict__ xs = X + i * P + lane_off;
+    const T* __restrict__ xs_next = X + ((i + istep < I) ? i + istep : i) * P + lane_off;
+    double s = 0.0;
+    // NACC independent accumulator chains (patch p goes to chain p % NACC): a wavefront's next MFMA does not have to wait for
+    // its previous one to leave the pipe
+    d4m_t accs[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) accs[n] = d4m_t{0.0, 0.0, 0.0, 0.0};
+    // CC: the chunk's position inside its j-block when that is known at compile time (register-resident WB), else -1
+    auto compute = [&](XV (&buf)[CH], int q, auto cc_tag) {
+      constexpr int CC = decltype(cc_tag)::value;
+      const int jb = BREG ? q / NPJ : q / npj, c = BREG ? CC : q - jb * npj;
+      if (BREG) {
+#pragma unroll
+        for (int p = 0; p < CH; ++p)
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            accs[p % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)buf[p].e[e], breg[(CC < 0 ? 0 : CC) * CH + p][e], accs[p % NACC], 0, 0, 0);
+      } else {
+        const double* __restrict__ sbc = sB + (size_t)(c * CH * 4 * V + V * kq) * RP + jr;
+#pragma unroll
+        for (int p = 0; p < CH; ++p)
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+            accs[p % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)buf[p].e[e], sbc[(size_t)(p * 4 * V + e) * RP], accs[p % NACC], 0, 0, 0);
+      }
+      if (c == npj - 1) {                                   // end of the j-block: fold WA in, start a fresh accumulator
+        const double* __restrict__ sa = sA + (size_t)(jb * 16 + kq) * RP + jr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          double d = accs[0][g];
+#pragma unroll
+          for (int n = 1; n < NACC; ++n) d += accs[n][g];
+          s = fma(sa[(size_t)(4 * g) * RP], d, s);
+        }
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) accs[n] = d4m_t{0.0, 0.0, 0.0, 0.0};
+      }
+    };
+    using C0 = std::integral_constant<int, BREG ? 0 : -1>;
+    using C1 = std::integral_constant<int, BREG ? (NPJ == 2 ? 1 : 0) : -1>;
+    for (int t = 0; t < npairs; ++t) {
+      const int q = 2 * t;
+      load(b1, xs, q + 1);
+      compute(b0, q, C0{});
+      const bool more = (q + 2 < nchunks);
+      load(b0, more ? xs : xs_next, more ? q + 2 : 0);
+      compute(b1, q + 1, C1{});
+    }
+    if (nchunks & 1) {                                      // an odd last chunk sits in b0; then fetch the next sample's first
+      compute(b0, nchunks - 1, C0{});
+      load(b0, xs_next, 0);
+    }
+    s += __shfl_xor(s, 16, kWave);
+    s += __shfl_xor(s, 32, kWave);
+    if (kq == 0 && jr < R) out[i * ldo + jr] = s;
+  }
+}
+
+
 template <typename T>
 static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, const double* WB, int R, double* out, int ldo,
                       hipStream_t st) {
@@ -122,6 +246,39 @@ static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, con
   const int rt = (R + 15) / 16;
   const size_t lds = (size_t)(A + B) * 16 * rt * sizeof(double);
   if (lds > kMttkrpLdsMax) { set_error("mttkrp: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
+#ifndef CMTFPLS_MTTKRP_TILE_ONLY
+  {
+    // the j-block form (round 3): whole samples per wavefront, WB as the plain B operand (registers or LDS)
+    constexpr int V = 16 / (int)sizeof(T);
+    const size_t lds1 = (size_t)(A + B) * 16 * sizeof(double);
+    const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    if (R <= 16 && A % 16 == 0 && aligned && lds1 <= kMttkrpLdsMax) {
+#ifndef CMTFPLS_MTTKRP_JK_GRID
+#define CMTFPLS_MTTKRP_JK_GRID 2048
+#endif
+      int grid = (int)((I + 3) / 4);
+      if (grid > CMTFPLS_MTTKRP_JK_GRID) grid = CMTFPLS_MTTKRP_JK_GRID;
+      const dim3 g(grid), b(256);
+#define JKL(CHH, NPJJ, BRG)                                                                                                   \
+  do {                                                                                                                        \
+    if (lds1 > 64 * 1024)                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mttkrp_jk_kernel<T, CHH, NPJJ, BRG>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);                                       \
+    hipLaunchKernelGGL((mttkrp_jk_kernel<T, CHH, NPJJ, BRG>), g, b, lds1, st, X, I, A, B, WA, WB, R, out, ldo);                \
+    return check_launch("mttkrp");                                                                                            \
+  } while (0)
+      const int npatch = (B % (4 * V) == 0) ? B / (4 * V) : 0;          // patches of 4 V columns per j-row
+#ifndef CMTFPLS_MTTKRP_NOBREG
+      if (npatch == 8) JKL(8, 1, true);                                 // 128 f32 / 64 f64: WB in 32 / 16 doubles per lane
+      if (npatch == 4) JKL(4, 1, true);
+      if (npatch == 16 && V == 2) JKL(8, 2, true);                      // 128 f64: 32 doubles per lane
+#endif
+      if (npatch > 0 && npatch % 8 == 0) JKL(8, 1, false);              // 256 f32 and beyond: WB from LDS, one read per MFMA
+      if (npatch > 0 && npatch % 4 == 0) JKL(4, 1, false);
+#undef JKL
+    }
+  }
+#endif
   const bool vec = (B % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) == 0);
   const int64_t ngroups = (I + 15) / 16;
   // Threads per workgroup (profiles/r02ap_mttkrp_nt.txt): the LDS share decides how many workgroups a CU holds; take the

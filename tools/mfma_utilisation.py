@@ -36,7 +36,7 @@ def main():
     acc = {}
     for row in csv.DictReader(open(cc)):
         name = row["Kernel_Name"]
-        for key in ("xcov_kernel<", "mttkrp_kernel<", "xcov_mixed_kernel<", "mttkrp_mixed_kernel<"):
+        for key in ("xcov_kernel<", "mttkrp_kernel<", "mttkrp_jk_kernel<", "xcov_mixed_kernel<", "mttkrp_mixed_kernel<"):
             if "cmtfpls::" + key in name:
                 rec = acc.setdefault(key[:-1], {}).setdefault(row["Dispatch_Id"], {})
                 rec[row["Counter_Name"]] = float(row["Counter_Value"])
