@@ -194,8 +194,12 @@ __global__ __launch_bounds__(256) void mttkrp_jk_kernel(const T* __restrict__ X,
 #pragma unroll
         for (int p = 0; p < CH; ++p)
 #pragma unroll
-          for (int e = 0; e < V; ++e)
+          for (int e = 0; e < V; ++e) {
+#ifdef CMTFPLS_MTTKRP_EXP_SKIP      // timing experiment only (wrong results): issue 1 of every EXP_SKIP MFMAs, all loads kept
+            if ((p * V + e) % CMTFPLS_MTTKRP_EXP_SKIP != 0) { asm volatile("" :: "v"(buf[p].e[e])); continue; }
+#endif
             accs[p % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)buf[p].e[e], breg[(CC < 0 ? 0 : CC) * CH + p][e], accs[p % NACC], 0, 0, 0);
+          }
       } else {
         const double* __restrict__ sbc = sB + (size_t)(c * CH * 4 * V + V * kq) * RP + jr;
 #pragma unroll
@@ -238,6 +242,222 @@ __global__ __launch_bounds__(256) void mttkrp_jk_kernel(const T* __restrict__ X,
 }
 
 
+// ---- round 3, second form: "k-row" -- the SAME MFMA count with fully coalesced loads ---------------------------------------
+//   M[i, r] = sum_k WB[k, r] * ( sum_j X[i, j, k] * WA[j, r] )
+// The matrix cores contract over j: one MFMA = 16 k's of ONE sample x 16 components x 4 consecutive j-rows,
+//   A operand  X[i][j0 + (l >> 4)][k]      lane (kk = l & 15, jq = l >> 4) loads the 16 bytes at column 16 V n + V kk of row
+//                                          j0 + jq: the 16 lanes of a row read 256 CONTIGUOUS bytes, the four rows of the step
+//                                          are contiguous too -- 8 cache lines per load instruction instead of the 64 half-lines
+//                                          of the j-block form (whose loads alone cap it at 6.06 TB/s, profiles/r03l_...)
+//   B operand  WA[j0 + (l >> 4)][r = l & 15]: ONE LDS word per j-step feeds all NL * V MFMAs of the step
+//   D[n][e]    (NL * V = 8 independent accumulators) row (l >> 4) + 4 g <-> k = k0 + 16 V n + V row + e
+// After the last j-step the 32 accumulator entries of a lane are multiplied by WB[k][r] (LDS) into one double and the four lane
+// groups are summed by two butterfly steps.  Trailing extents beyond NL * 16 V elements are taken in passes of that width
+// (256 x 256 f32: two passes over the sample's rows, each reading its half of every row: 512 contiguous bytes per row).
+// Shapes: B % (NL * 16 V) == 0, A % (4 * CHJ) == 0 (CHJ = 8 / NL j-steps per register buffer), R <= 16.
+template <typename T, int NL>
+__global__ __launch_bounds__(256) void mttkrp_kj_kernel(const T* __restrict__ X, int64_t I, int A, int B,
+                                                        const double* __restrict__ WA, const double* __restrict__ WB, int R,
+                                                        double* __restrict__ out, int ldo) {
+  constexpr int V = VecOf<T>::N;
+  constexpr int RP = 16;
+  constexpr int CHJ = 8 / NL;               // j-steps per buffer: 8 loads (8 KB per wavefront) in flight per buffer
+  constexpr int KP = NL * 16 * V;           // k's per pass
+  extern __shared__ double lds[];          // sA[A][16] then sB[B][16], zero padded beyond R
+  double* sA = lds;
+  double* sB = lds + (size_t)A * RP;
+  for (int idx = threadIdx.x; idx < A * RP; idx += 256) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
+  for (int idx = threadIdx.x; idx < B * RP; idx += 256) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kk = lane & 15, jq = lane >> 4;
+  const int64_t P = (int64_t)A * B;
+  const int npass = B / KP, cpp = A / (4 * CHJ);          // passes per sample, chunks per pass
+  const int nchunks = npass * cpp, npairs = nchunks / 2;
+  const int64_t istep = (int64_t)gridDim.x * 4;
+  using XV = Pack<T, V>;
+  XV b0[CHJ][NL], b1[CHJ][NL];
+  // chunk q of a sample: pass q / cpp, j-steps [CHJ (q % cpp), +CHJ)
+  auto load = [&](XV (&buf)[CHJ][NL], const T* __restrict__ xs, int q) {
+    const int ps = q / cpp, c = q - ps * cpp;
+    const T* __restrict__ xp = xs + (int64_t)(c * CHJ * 4) * B + ps * KP;
+#pragma unroll
+    for (int h = 0; h < CHJ; ++h)
+#pragma unroll
+      for (int n = 0; n < NL; ++n) buf[h][n] = ld_stream(reinterpret_cast<const XV*>(xp + (int64_t)(h * 4) * B + n * 16 * V));
+  };
+  int64_t i = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t lane_off = (int64_t)jq * B + V * kk;       // row jq of the j-step, columns V kk .. V kk + V - 1 of the load
+  if (i < I) load(b0, X + i * P + lane_off, 0);
+  for (; i < I; i += istep) {
+    const T* __restrict__ xs = X + i * P + lane_off;
+    const T* __restrict__ xs_next = X + ((i + istep < I) ? i + istep : i) * P + lane_off;
+    double s = 0.0;
+    d4m_t acc[NL][V];
+#pragma unroll
+    for (int n = 0; n < NL; ++n)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[n][e] = d4m_t{0.0, 0.0, 0.0, 0.0};
+    auto compute = [&](XV (&buf)[CHJ][NL], int q) {
+      const int ps = q / cpp, c = q - ps * cpp;
+      const double* __restrict__ sa = sA + (size_t)(c * CHJ * 4 + jq) * RP + kk;   // (kk = l & 15 doubles as the component index r)
+#pragma unroll
+      for (int h = 0; h < CHJ; ++h) {
+        const double wa = sa[(size_t)(h * 4) * RP];
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+#ifdef CMTFPLS_MTTKRP_EXP_SKIP      // timing experiment only (wrong results): issue 1 of every EXP_SKIP MFMAs, all loads kept
+            if (((h * NL + n) * V + e) % CMTFPLS_MTTKRP_EXP_SKIP != 0) { asm volatile("" :: "v"(buf[h][n].e[e])); continue; }
+#endif
+            acc[n][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)buf[h][n].e[e], wa, acc[n][e], 0, 0, 0);
+          }
+      }
+      if (c == cpp - 1) {                                 // end of the pass: fold WB in, start fresh accumulators
+        const double* __restrict__ sb = sB + (size_t)(ps * KP) * RP + kk;
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s = fma(sb[(size_t)(n * 16 * V + V * (jq + 4 * g) + e) * RP], acc[n][e][g], s);
+            acc[n][e] = d4m_t{0.0, 0.0, 0.0, 0.0};
+          }
+      }
+    };
+    for (int t = 0; t < npairs; ++t) {
+      const int q = 2 * t;
+      load(b1, xs, q + 1);
+      compute(b0, q);
+      const bool more = (q + 2 < nchunks);
+      load(b0, more ? xs : xs_next, more ? q + 2 : 0);
+      compute(b1, q + 1);
+    }
+    if (nchunks & 1) {
+      compute(b0, nchunks - 1);
+      load(b0, xs_next, 0);
+    }
+    s += __shfl_xor(s, 16, kWave);
+    s += __shfl_xor(s, 32, kWave);
+    if (jq == 0 && kk < R) out[i * ldo + kk] = s;
+  }
+}
+
+
+// ---- round 3, third form: the k-row form on v_mfma_f64_4x4x4_4b_f64 for R <= 12 -------------------------------------------------
+// With f32 storage the k-row form above is bound by the f64 matrix pipe, not by memory: with half of its MFMAs removed it runs at
+// 6.6 TB/s, with all of them at 5.2-5.6 (profiles/r03o_mttkrp_forms.txt) -- and 6 of the 16 columns of every 16x16x4 tile are
+// padding when R = 10.  The 4x4x4 form (four independent 4 x 4 x 4 blocks per instruction, same FLOP rate:
+// profiles/r03d_mfma_f64_rate.txt) lets the components be taken in groups of FOUR: NG = ceil(R / 4) groups, 12 columns for R = 10.
+// Operand layout (probed on the device, profiles/r03e_mfma_f64_4x4_layout.txt): A[blk][i][k] in lane i + 4 blk + 16 k,
+// B[blk][k][j] in lane j + 4 blk + 16 k, D[blk][i][j] in lane j + 4 blk + 16 i.  Mapping: contraction index = j-row (l >> 4),
+// (i, blk) = the 16 k's of a load (l & 15: the SAME loads and lane map as the k-row form), matrix column = component 4 g + (l & 3):
+//   A operand  X[i][j0 + (l >> 4)][k(l & 15)]                     one register, shared by the NG MFMAs of the groups
+//   B operand  WA[j0 + (l >> 4)][4 g + (l & 3)]                   NG LDS words per j-step (the same for the four blocks)
+//   D[n][e][g] lane l' holds k-row (l' >> 4) + 4 ((l' >> 2) & 3), component 4 g + (l' & 3)
+template <typename T, int NL, int NG>
+__global__ __launch_bounds__(256) void mttkrp_kj4_kernel(const T* __restrict__ X, int64_t I, int A, int B,
+                                                         const double* __restrict__ WA, const double* __restrict__ WB, int R,
+                                                         double* __restrict__ out, int ldo) {
+  constexpr int V = VecOf<T>::N;
+  constexpr int RP = 16;
+  constexpr int CHJ = 8 / NL;
+  constexpr int KP = NL * 16 * V;
+  extern __shared__ double lds[];          // sA[A][16] then sB[B][16], zero padded beyond R
+  double* sA = lds;
+  double* sB = lds + (size_t)A * RP;
+  for (int idx = threadIdx.x; idx < A * RP; idx += 256) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? WA[(int64_t)j * R + r] : 0.0; }
+  for (int idx = threadIdx.x; idx < B * RP; idx += 256) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kk = lane & 15, jq = lane >> 4, jn = lane & 3;
+  const int krow = (lane >> 4) + 4 * ((lane >> 2) & 3);   // the k-row this lane's accumulator entries belong to
+  const int64_t P = (int64_t)A * B;
+  const int npass = B / KP, cpp = A / (4 * CHJ);
+  const int nchunks = npass * cpp, npairs = nchunks / 2;
+  const int64_t istep = (int64_t)gridDim.x * 4;
+  using XV = Pack<T, V>;
+  XV b0[CHJ][NL], b1[CHJ][NL];
+  auto load = [&](XV (&buf)[CHJ][NL], const T* __restrict__ xs, int q) {
+    const int ps = q / cpp, c = q - ps * cpp;
+    const T* __restrict__ xp = xs + (int64_t)(c * CHJ * 4) * B + ps * KP;
+#pragma unroll
+    for (int h = 0; h < CHJ; ++h)
+#pragma unroll
+      for (int n = 0; n < NL; ++n) buf[h][n] = ld_stream(reinterpret_cast<const XV*>(xp + (int64_t)(h * 4) * B + n * 16 * V));
+  };
+  int64_t i = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t lane_off = (int64_t)jq * B + V * kk;
+  if (i < I) load(b0, X + i * P + lane_off, 0);
+  for (; i < I; i += istep) {
+    const T* __restrict__ xs = X + i * P + lane_off;
+    const T* __restrict__ xs_next = X + ((i + istep < I) ? i + istep : i) * P + lane_off;
+    double s[NG];
+    double acc[NL][V][NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) s[g] = 0.0;
+#pragma unroll
+    for (int n = 0; n < NL; ++n)
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[n][e][g] = 0.0;
+    auto compute = [&](XV (&buf)[CHJ][NL], int q) {
+      const int ps = q / cpp, c = q - ps * cpp;
+      const double* __restrict__ sa = sA + (size_t)(c * CHJ * 4 + jq) * RP + jn;
+#pragma unroll
+      for (int h = 0; h < CHJ; ++h) {
+        double wa[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) wa[g] = sa[(size_t)(h * 4) * RP + 4 * g];
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const double a = (double)buf[h][n].e[e];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[n][e][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, wa[g], acc[n][e][g], 0, 0, 0);
+          }
+      }
+      if (c == cpp - 1) {                                 // end of the pass: fold WB in, start fresh accumulators
+        const double* __restrict__ sb = sB + (size_t)(ps * KP + V * krow) * RP + jn;
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+          for (int e = 0; e < V; ++e)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              s[g] = fma(sb[(size_t)(n * 16 * V + e) * RP + 4 * g], acc[n][e][g], s[g]);
+              acc[n][e][g] = 0.0;
+            }
+      }
+    };
+    for (int t = 0; t < npairs; ++t) {
+      const int q = 2 * t;
+      load(b1, xs, q + 1);
+      compute(b0, q);
+      const bool more = (q + 2 < nchunks);
+      load(b0, more ? xs : xs_next, more ? q + 2 : 0);
+      compute(b1, q + 1);
+    }
+    if (nchunks & 1) {
+      compute(b0, nchunks - 1);
+      load(b0, xs_next, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {                        // the 16 lanes that share (l & 3): four butterfly steps
+      double v = s[g];
+      v += __shfl_xor(v, 4, kWave);
+      v += __shfl_xor(v, 8, kWave);
+      v += __shfl_xor(v, 16, kWave);
+      v += __shfl_xor(v, 32, kWave);
+      if (lane < 4 && 4 * g + jn < R) out[i * ldo + 4 * g + jn] = v;
+    }
+  }
+}
+
+
 template <typename T>
 static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, const double* WB, int R, double* out, int ldo,
                       hipStream_t st) {
@@ -267,6 +487,46 @@ static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, con
     hipLaunchKernelGGL((mttkrp_jk_kernel<T, CHH, NPJJ, BRG>), g, b, lds1, st, X, I, A, B, WA, WB, R, out, ldo);                \
     return check_launch("mttkrp");                                                                                            \
   } while (0)
+#ifndef CMTFPLS_MTTKRP_NO_KJ
+      // the k-row form first (coalesced loads): f32 128 / 256 / ... columns per row (NL = 2), 64 (NL = 1); f64 128+ (NL = 4), 64 (NL = 2)
+#define KJL(NLL)                                                                                                              \
+  do {                                                                                                                        \
+    if (lds1 > 64 * 1024)                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mttkrp_kj_kernel<T, NLL>),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);                                       \
+    hipLaunchKernelGGL((mttkrp_kj_kernel<T, NLL>), g, b, lds1, st, X, I, A, B, WA, WB, R, out, ldo);                           \
+    return check_launch("mttkrp");                                                                                            \
+  } while (0)
+#define KJ4(NLL, NGG)                                                                                                         \
+  do {                                                                                                                        \
+    if (lds1 > 64 * 1024)                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mttkrp_kj4_kernel<T, NLL, NGG>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);                                       \
+    hipLaunchKernelGGL((mttkrp_kj4_kernel<T, NLL, NGG>), g, b, lds1, st, X, I, A, B, WA, WB, R, out, ldo);                     \
+    return check_launch("mttkrp");                                                                                            \
+  } while (0)
+#define KJ4N(NLL)                                                                                                             \
+  do {                                                                                                                        \
+    if (R <= 4) KJ4(NLL, 1); else if (R <= 8) KJ4(NLL, 2); else KJ4(NLL, 3);                                                  \
+  } while (0)
+      {
+        constexpr int NLW = (V == 4) ? 2 : 4, NLH = NLW / 2;            // loads per j-step: 128 columns per pass, or 64
+        const bool wide = B % (NLW * 16 * V) == 0 && A % (4 * (8 / NLW)) == 0;
+        const bool half = B % (NLH * 16 * V) == 0 && A % (4 * (8 / NLH)) == 0;
+#ifndef CMTFPLS_MTTKRP_NO_KJ4
+        // f32 storage, R <= 12: the 4x4x4 form (the 16x16x4 one is matrix-pipe bound there; f64 storage is memory bound either way)
+        if (V == 4 && R <= 12) {
+          if (wide) KJ4N(NLW);
+          if (half) KJ4N(NLH);
+        }
+#endif
+        if (wide) KJL(NLW);
+        if (half) KJL(NLH);
+      }
+#undef KJ4N
+#undef KJ4
+#undef KJL
+#endif
       const int npatch = (B % (4 * V) == 0) ? B / (4 * V) : 0;          // patches of 4 V columns per j-row
 #ifndef CMTFPLS_MTTKRP_NOBREG
       if (npatch == 8) JKL(8, 1, true);                                 // 128 f32 / 64 f64: WB in 32 / 16 doubles per lane

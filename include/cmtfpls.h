@@ -147,8 +147,10 @@ int cmtfpls_mttkrp_f32_mixed(const float* X, int64_t I, int A, int B, const doub
                              double* out, int ldo, void* stream);
 
 /* mttkrp: M (I x R, leading dim ldo) = X_(0) (WA (.) WB), M[i, r] = sum_c X[i,c] WA[c / B, r] WB[c % B, r],
- * WA (A x R) and WB (B x R) row-major f64, R <= 32, on the f64 matrix cores with the Khatri-Rao
- * operand formed on the fly in LDS.  One pass over X replaces the R project-and-deflate passes of
+ * WA (A x R) and WB (B x R) row-major f64, R <= 32, on the f64 matrix cores; the Khatri-Rao operand is never
+ * materialised (round 3: for A % 16 == 0, B % 64 == 0, R <= 16 the matrix cores contract over one trailing mode with the
+ * plain loading of that mode as operand and the other mode's loading is folded into the accumulators; otherwise the
+ * product WA[j,r] WB[k,r] is formed from LDS per tile).  One pass over X replaces the R project-and-deflate passes of
  * predict / transform (tpls.py:133-142, 156-165) when X has no NaN:
  * T = M (I + triu(W^T W, 1))^{-1} (the R x R part is done by the caller).
  * CMTFPLS_EUNSUPPORTED when R > 32 or (A + B) * 16 * ceil(R / 16) doubles exceed 152 KB of LDS. */

@@ -390,7 +390,13 @@ def test_xcov_identities_and_quadform(be):
                                      ((50, 128, 128), 10), ((29, 5, 4), 16), ((70, 12, 8), 17), ((300, 16, 16), 32),
                                      # I % 16 == 0 and 512-byte multiples of columns: the coalesced LDS-tile form (1 and 2 component tiles,
                                      # several chunks per row, a matrix block, KronWalk carries)
-                                     ((64, 128, 128), 10), ((48, 16, 16), 20), ((32, 1, 512), 3), ((80, 24, 16), 16), ((16, 256, 256), 10)])
+                                     ((64, 128, 128), 10), ((48, 16, 16), 20), ((32, 1, 512), 3), ((80, 24, 16), 16), ((16, 256, 256), 10),
+                                     # round 3, one case per form and instance: k-row on 4x4x4 MFMAs (f32, R <= 12: 1 / 2 / 3 component
+                                     # groups; 128- and 64-column passes, two passes at 256 columns, ragged sample count), k-row on
+                                     # 16x16x4 (R = 13-16, and every f64 case), j-block (A % 32 != 0 at 64 columns; 48 columns), tile (rest)
+                                     ((37, 128, 128), 3), ((21, 32, 128), 7), ((19, 16, 256), 12), ((23, 32, 64), 10), ((9, 64, 64), 4),
+                                     ((41, 128, 128), 14), ((17, 16, 384), 16), ((13, 32, 64), 15),
+                                     ((11, 48, 64), 9), ((27, 16, 48), 6), ((7, 80, 32), 5)])
 def test_mttkrp_mfma(be, shape, R, dt):
     """M = X_(0) (WA (.) WB) on the f64 matrix cores, Khatri-Rao operand formed in LDS, against NumPy
     (asymmetric random data: checks the A/B/D lane maps; ragged rows, odd B, 1 and 2 component tiles)."""

@@ -250,7 +250,7 @@ def test_coupled_nan_transform_from_one_read(api, monkeypatch, dtype):
 
 # ---- the whole small fit in one launch (VERDICT r2 "Next" #8) ------------------------------------------------------------------
 @pytest.mark.small_fit
-@pytest.mark.parametrize("shape,M,R", [((200, 10, 8), 4, 3), ((120, 40), 3, 4), ((64, 7, 33), 1, 16), ((300, 12, 12), 16, 5)])
+@pytest.mark.parametrize("shape,M,R", [((200, 10, 8), 4, 3), ((120, 40), 3, 4), ((64, 7, 33), 1, 16), ((200, 12, 12), 16, 5)])
 def test_small_fit_in_one_launch_equals_the_regular_engine(api, monkeypatch, shape, M, R):
     """BASELINE configs[0] and neighbours: tPLS.fit of a small float64 problem is ONE kernel launch (cmtfpls_fit_small_f64);
     same iteration counts, factors equal to the multi-launch engine to 1e-12 and to the oracle."""

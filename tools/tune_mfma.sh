@@ -4,7 +4,12 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
-if [ "${SET:-r2}" = jk ]; then   # round 3: forms of the j-block MTTKRP
+if [ "${SET:-r2}" = forms ]; then   # round 3: the four MTTKRP forms
+VARIANTS=("m_base:" "m_kj16:-DCMTFPLS_MTTKRP_NO_KJ4" "m_jk:-DCMTFPLS_MTTKRP_NO_KJ" "m_tile:-DCMTFPLS_MTTKRP_TILE_ONLY")
+elif [ "${SET:-r2}" = skip ]; then   # round 3 timing experiment: what does the j-block MTTKRP cost with 1/2, 1/4, 0 of its MFMAs?
+VARIANTS=("m_base:" "m_skip2:-DCMTFPLS_MTTKRP_EXP_SKIP=2" "m_skip4:-DCMTFPLS_MTTKRP_EXP_SKIP=4" "m_skip32:-DCMTFPLS_MTTKRP_EXP_SKIP=32"
+          "m_jk:-DCMTFPLS_MTTKRP_NO_KJ" "m_jkskip32:-DCMTFPLS_MTTKRP_NO_KJ -DCMTFPLS_MTTKRP_EXP_SKIP=32" "m_tile:-DCMTFPLS_MTTKRP_TILE_ONLY")
+elif [ "${SET:-r2}" = jk ]; then   # round 3: forms of the j-block MTTKRP
 VARIANTS=("m_base:" "m_nobreg:-DCMTFPLS_MTTKRP_NOBREG" "m_acc2:-DCMTFPLS_MTTKRP_NACC=2" "m_acc4:-DCMTFPLS_MTTKRP_NACC=4"
           "m_acc4nobreg:-DCMTFPLS_MTTKRP_NACC=4 -DCMTFPLS_MTTKRP_NOBREG" "m_tile:-DCMTFPLS_MTTKRP_TILE_ONLY")
 else
