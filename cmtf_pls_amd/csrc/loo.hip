@@ -46,6 +46,7 @@ struct LooArgs {
   double* ymean_out;      // (M)
   int* flag_out;          // set to 1 when X or Y holds a non-finite value (the caller then takes the regular engine)
   double* T_whole;        // (I, R) X scores (whole fit)
+  int64_t lds_xy_offset;  // > 0: the centred X (I * P) and Y (I * M) are kept in LDS, this many doubles into the dynamic allocation
 };
 
 // sum over the workgroup; every thread gets the same value; two barriers, so back-to-back calls may share `red`
@@ -165,6 +166,12 @@ __global__ __launch_bounds__(NT) void loo_tpls_kernel(LooArgs a) {
   if (!whole && (blockIdx.x >= a.nfolds || fold >= I)) return;
   double* Xf = a.ws + (int64_t)blockIdx.x * a.ws_per_fold;
   double* Yf = Xf + (int64_t)I * P;
+  // whole fit of a problem whose centred copies fit next to the vectors: X and Y live in LDS for the whole fit (the tail of the
+  // dynamic allocation, a.lds_xy_offset doubles in) -- every sweep of an iteration is then an LDS sweep instead of an L2 one
+  if (whole && a.lds_xy_offset > 0) {
+    Xf = sm + a.lds_xy_offset;
+    Yf = Xf + (int64_t)I * P;
+  }
   double* T = whole ? a.T_whole : Yf + (int64_t)I * M;
   // LDS carve-up
   double* u = sm;
@@ -464,6 +471,7 @@ int cmtfpls_loo_tpls_f64(const double* X, const double* Y, const double* colsum_
   a.I = I; a.A = A; a.B = B; a.M = M; a.R = R; a.max_iter = max_iter; a.fold0 = fold0; a.nfolds = nfolds; a.tol = tol;
   a.whole = 0;
   a.T_whole = nullptr;
+  a.lds_xy_offset = 0;
   a.U_out = a.WA_out = a.WB_out = a.Q_out = a.coef_out = a.ssq_out = a.xmean_out = a.ymean_out = nullptr;
   a.flag_out = nullptr;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -485,11 +493,15 @@ int cmtfpls_fit_small_f64(const double* X, const double* Y, int I, int A, int B,
     return CMTFPLS_EINVAL;
   }
   const int n = A < B ? A : B;
-  const size_t lds = loo_lds_bytes(I, A, B, M, R, 1024);
+  size_t lds = loo_lds_bytes(I, A, B, M, R, 1024);
   if (n > kLooMaxN || M > kLooMaxM || R > kLooMaxR || lds > 150 * 1024) {
     set_error("fit_small: shape outside the one-workgroup form; use the regular engine");
     return CMTFPLS_EUNSUPPORTED;
   }
+  // the centred copies of X and Y in LDS too when everything fits 158 KB (BASELINE configs[0]: 128 KB + 6 KB + 19 KB)
+  const size_t xy = ((size_t)I * A * B + (size_t)I * M) * sizeof(double);
+  const int64_t xy_off = (lds + xy <= 158 * 1024) ? (int64_t)(lds / sizeof(double)) : 0;
+  if (xy_off > 0) lds += xy;
   if (!ws || ws_bytes < cmtfpls_fit_small_workspace_bytes(I, A, B, M)) { set_error("fit_small: workspace too small"); return CMTFPLS_EWORKSPACE; }
   // workspace: Xf (I * P) | Yf (I * M); the kernel's third slot (T, I x R) is the caller's output buffer
   LooArgs a;
@@ -498,6 +510,7 @@ int cmtfpls_fit_small_f64(const double* X, const double* Y, int I, int A, int B,
   a.I = I; a.A = A; a.B = B; a.M = M; a.R = R; a.max_iter = max_iter; a.fold0 = 0; a.nfolds = 1; a.tol = tol;
   a.whole = 1;
   a.T_whole = T;
+  a.lds_xy_offset = xy_off;
   a.U_out = U; a.WA_out = WA; a.WB_out = WB; a.Q_out = Q; a.coef_out = coef; a.ssq_out = ssq; a.xmean_out = x_mean; a.ymean_out = y_mean;
   a.flag_out = flag;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -507,7 +507,7 @@ static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, con
   } while (0)
 #define KJ4N(NLL)                                                                                                             \
   do {                                                                                                                        \
-    if (R <= 4) KJ4(NLL, 1); else if (R <= 8) KJ4(NLL, 2); else KJ4(NLL, 3);                                                  \
+    if (R <= 4) KJ4(NLL, 1); else if (R <= 8) KJ4(NLL, 2); else if (R <= 12) KJ4(NLL, 3); else KJ4(NLL, 4);                   \
   } while (0)
       {
         constexpr int NLW = (V == 4) ? 2 : 4, NLH = NLW / 2;            // loads per j-step: 128 columns per pass, or 64
@@ -515,7 +515,10 @@ static int run_mttkrp(const T* X, int64_t I, int A, int B, const double* WA, con
         const bool half = B % (NLH * 16 * V) == 0 && A % (4 * (8 / NLH)) == 0;
 #ifndef CMTFPLS_MTTKRP_NO_KJ4
         // f32 storage, R <= 12: the 4x4x4 form (the 16x16x4 one is matrix-pipe bound there; f64 storage is memory bound either way)
-        if (V == 4 && R <= 12) {
+#ifndef CMTFPLS_MTTKRP_KJ4_MAXR
+#define CMTFPLS_MTTKRP_KJ4_MAXR 12
+#endif
+        if (V == 4 && R <= CMTFPLS_MTTKRP_KJ4_MAXR) {
           if (wide) KJ4N(NLW);
           if (half) KJ4N(NLH);
         }

@@ -228,7 +228,7 @@ class NipalsEngine:
 
     # fits below this many elements of X go through ONE launch when the shape allows it: a regular iteration is ~20
     # launches of pure latency whatever the size, a one-workgroup iteration costs time in proportion to I * P
-    small_fit_elements = 1 << 15    # measured (profiles/r03d_small_fit.txt): 2.2x faster at 16000 elements, slower from 65536 on
+    small_fit_elements = 1 << 15    # measured (profiles/r03q_small_fit.txt): 2.2x faster at 16000 elements, slower from 65536 on
     small_fit = True
 
     def _fit_small(self, Xs, Y, n_components, tol, max_iter, coupled, verbose, on_preprocessed) -> Optional[FitState]:

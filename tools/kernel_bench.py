@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--only", default="all")
+    ap.add_argument("--R", type=int, default=10, help="components of the MTTKRP")
     args = ap.parse_args()
     I, A, B = args.shape
     P = A * B
@@ -58,13 +59,13 @@ def main():
     if args.only == "mfma":
         S = be.empty(args.M, P)
         rec(f"xcov S=X^T Y (M={args.M}, f64 MFMA)", lambda: be.xcov(X, Y, False, out=S), xbytes)
-        WAm = torch.randn(A, 10, device="cuda:0", dtype=torch.float64, generator=g)
-        WBm = torch.randn(B, 10, device="cuda:0", dtype=torch.float64, generator=g)
-        Mo = be.empty(I, 10)
-        rec("mttkrp X(WA.WB) (R=10, f64 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo), xbytes)
+        WAm = torch.randn(A, args.R, device="cuda:0", dtype=torch.float64, generator=g)
+        WBm = torch.randn(B, args.R, device="cuda:0", dtype=torch.float64, generator=g)
+        Mo = be.empty(I, args.R)
+        rec(f"mttkrp X(WA.WB) (R={args.R}, f64 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo), xbytes)
         if args.dtype == "f32":
             rec(f"xcov mixed (M={args.M}, f32 MFMA)", lambda: be.xcov(X, Y, False, out=S, mixed=True), xbytes)
-            rec("mttkrp mixed (R=10, f32 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo, mixed=True), xbytes)
+            rec(f"mttkrp mixed (R={args.R}, f32 MFMA)", lambda: be.mttkrp(X, A, B, WAm, WBm, Mo, mixed=True), xbytes)
         return
     if args.only == "contract":
         rec("mode0_contract", lambda: be.mode0_contract(X, u, False, out=Z), xbytes)

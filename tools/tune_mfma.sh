@@ -5,7 +5,8 @@ ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/cmtf_pls_amd/csrc"
 OUT="$ROOT/cmtf_pls_amd/lib/variants"
 if [ "${SET:-r2}" = forms ]; then   # round 3: the four MTTKRP forms
-VARIANTS=("m_base:" "m_kj16:-DCMTFPLS_MTTKRP_NO_KJ4" "m_jk:-DCMTFPLS_MTTKRP_NO_KJ" "m_tile:-DCMTFPLS_MTTKRP_TILE_ONLY")
+VARIANTS=("m_base:" "m_kj16:-DCMTFPLS_MTTKRP_NO_KJ4" "m_jk:-DCMTFPLS_MTTKRP_NO_KJ" "m_tile:-DCMTFPLS_MTTKRP_TILE_ONLY"
+          "m_kj4r16:-DCMTFPLS_MTTKRP_KJ4_MAXR=16")     # the 4x4x4 form with FOUR component groups (same flops as the 16x16x4 tile)
 elif [ "${SET:-r2}" = skip ]; then   # round 3 timing experiment: what does the j-block MTTKRP cost with 1/2, 1/4, 0 of its MFMAs?
 VARIANTS=("m_base:" "m_skip2:-DCMTFPLS_MTTKRP_EXP_SKIP=2" "m_skip4:-DCMTFPLS_MTTKRP_EXP_SKIP=4" "m_skip32:-DCMTFPLS_MTTKRP_EXP_SKIP=32"
           "m_jk:-DCMTFPLS_MTTKRP_NO_KJ" "m_jkskip32:-DCMTFPLS_MTTKRP_NO_KJ -DCMTFPLS_MTTKRP_EXP_SKIP=32" "m_tile:-DCMTFPLS_MTTKRP_TILE_ONLY")
