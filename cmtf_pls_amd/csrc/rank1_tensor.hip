@@ -1,4 +1,4 @@
-// Rank-1 CP factors of a cross-covariance TENSOR Z of order 3 or 4 (X of order 4 or 5):
+// Rank-1 CP factors of a cross-covariance TENSOR Z of order 3 to 7 (X of order 4 to 8; round 2: order 3 or 4):
 //   parafac(Z, 1, tol=tol, init="svd", normalize_factors=True)[1]      tpls.py:86-88, cmtf.py:100-102
 // restated from tensorly 0.9.0's published algorithm exactly as oracle/nipals_oracle.py does
 // (value-level parity with tensorly itself is UNPINNED):
@@ -14,10 +14,10 @@
 
 namespace cmtfpls {
 
-constexpr int kMaxOrder = 4;
+constexpr int kMaxOrder = 7;
 
 struct TensorDims {
-  int n;                 // order of Z (3 or 4)
+  int n;                 // order of Z (3 .. kMaxOrder)
   int d[kMaxOrder];      // dims
   int64_t stride[kMaxOrder];
   int64_t total;
@@ -193,7 +193,7 @@ size_t cmtfpls_rank1_tensor_workspace_bytes(const int* dims, int n) {
 int cmtfpls_rank1_tensor_f64(const double* Z, const int* dims, int n, double tol, double* factors, int ld,
                              double* info, int n_squarings, void* ws, size_t ws_bytes, void* stream) {
   TensorDims td;
-  if (!Z || !dims || !factors || !make_dims(dims, n, &td)) { set_error("rank1_tensor: bad argument (order 3 or 4)"); return CMTFPLS_EINVAL; }
+  if (!Z || !dims || !factors || !make_dims(dims, n, &td)) { set_error("rank1_tensor: bad argument (order 3 to 7)"); return CMTFPLS_EINVAL; }
   size_t maxd = 0, sumd = 0;
   for (int m = 0; m < n; ++m) {
     if ((size_t)td.d[m] > maxd) maxd = td.d[m];

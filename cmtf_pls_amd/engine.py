@@ -77,7 +77,7 @@ def split_trailing(shape: Sequence[int]):
 MAX_COMPONENTS = 1024          # cmtfpls_normal_solve_ws_f64: the (a+1) x (a+1) normal equations in one workgroup
 MAX_RANK1_SIDE = 4096          # cmtfpls_rank1_f64: min(J, K) of an order-3 block (Gram squaring of the smaller side)
 MAX_TENSOR_MODE = 1024         # cmtfpls_rank1_tensor_f64: every trailing mode of an order-4/5 block
-MAX_ORDER = 5
+MAX_ORDER = 8                  # cmtfpls_rank1_tensor_f64 takes cross-covariance tensors of order <= 7
 
 
 def validate_limits(shapes, n_components: int) -> None:
@@ -90,7 +90,7 @@ def validate_limits(shapes, n_components: int) -> None:
     for shape in shapes:
         order = len(shape)
         if order > MAX_ORDER:
-            raise NotImplementedError("X blocks of order > 5 are not supported")
+            raise NotImplementedError(f"X blocks of order > {MAX_ORDER} are not supported")
         if order == 3 and min(shape[1:]) > MAX_RANK1_SIDE:
             raise ValueError(f"X block {tuple(shape)}: min(J, K) = {min(shape[1:])} exceeds the rank-1 kernel's limit of {MAX_RANK1_SIDE}")
         if order >= 4 and max(shape[1:]) > MAX_TENSOR_MODE:
@@ -175,8 +175,8 @@ class NipalsEngine:
         elif order == 3:
             self.be.rank1(Z, blk.A, blk.B, wA, wB, info=info, n_squarings=n_squarings)
         else:
-            if order > 5:
-                raise NotImplementedError("X blocks of order > 5 are not supported")
+            if order > MAX_ORDER:
+                raise NotImplementedError(f"X blocks of order > {MAX_ORDER} are not supported")
             dims = blk.shape[1:]
             self.be.rank1_tensor(Z, dims, tol, fac, info=info, n_squarings=None)
             wA.copy_(fac[0, : dims[0]])

@@ -92,7 +92,7 @@ size_t cmtfpls_rank1_workspace_bytes(int A, int B);
 int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
                       int n_squarings, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_normalize_f64(double* v, int64_t n, double* nrm, void* stream);
-/* rank1_tensor: the same parafac call when Z is a TENSOR of order n = 3 or 4 (X of order 4 or 5,
+/* rank1_tensor: the same parafac call when Z is a TENSOR of order n = 3 .. 7 (X of order 4 .. 8; orders 4 and 5 are
  * exercised by tests/test_cmtf.py:18-21, tests/test_tpls.py:132-155): leading-left-singular-vector
  * init of every unfolding, ALS sweeps, stop when |d rec_error| < tol from the 2nd sweep on (<= 100
  * sweeps), as tensorly 0.9.0 publishes it.  dims: HOST array of the n mode sizes (each <= 1024);

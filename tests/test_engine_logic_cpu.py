@@ -396,8 +396,8 @@ def test_limits_are_validated_before_the_backend_is_touched():
         eng.begin([torch.zeros(6, 3, 3)], Y, engine.MAX_COMPONENTS + 1, coupled=False)
     with pytest.raises(ValueError, match="n_components"):
         eng.begin([torch.zeros(6, 3, 3)], Y, 0, coupled=False)
-    with pytest.raises(NotImplementedError, match="order > 5"):
-        eng.begin([torch.zeros(6, 2, 2, 2, 2, 2)], Y, 1, coupled=False)
+    with pytest.raises(NotImplementedError, match="order > 8"):
+        eng.begin([torch.zeros(6, 2, 2, 2, 2, 2, 2, 2, 2)], Y, 1, coupled=False)
     with pytest.raises(ValueError, match="rank-1 kernel"):
         engine.validate_limits([(6, engine.MAX_RANK1_SIDE + 1, engine.MAX_RANK1_SIDE + 5)], 2)
     with pytest.raises(ValueError, match="trailing mode"):

@@ -102,8 +102,8 @@ def test_limits_raise_before_any_sweep(api, monkeypatch):
     from cmtf_pls_amd.backend import HipBackend
     orig = HipBackend.colstats
     monkeypatch.setattr(HipBackend, "colstats", lambda self, X2: (calls.append(1), orig(self, X2))[1])
-    x = torch.zeros(4, 2, 2, 2, 2, 2, device="cuda:0")            # order 6
-    with pytest.raises(NotImplementedError, match="order > 5"):
+    x = torch.zeros(4, 2, 2, 2, 2, 2, 2, 2, 2, device="cuda:0")   # order 9
+    with pytest.raises(NotImplementedError, match="order > 8"):
         api.tPLS(1).fit(x, torch.zeros(4, 1, dtype=torch.float64))
     with pytest.raises(ValueError, match="n_components"):
         api.tPLS(engine.MAX_COMPONENTS + 1).fit(torch.zeros(8, 4, 4, device="cuda:0"), torch.zeros(8, 1, dtype=torch.float64))
@@ -296,3 +296,26 @@ def test_small_fit_declines_missing_values_and_large_inputs(api, monkeypatch):
     calls["fit_small"] = 0
     api.tPLS(2).fit(big, yb)
     assert calls["fit_small"] == 0
+
+
+# ---- X of order 6 and 7 (round 2 stopped at 5; tpls.py:84-90 has no limit) ---------------------------------------------------
+@pytest.mark.parametrize("shape", [(40, 3, 4, 2, 3, 2), (30, 2, 3, 2, 2, 3, 2)])
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_fit_of_order_6_and_7_tensors(api, shape, algorithm):
+    x, y, _ = O.import_synthetic(shape, 3, 2, error=0.1, seed=17)
+    m = api.tPLS(2, algorithm=algorithm)
+    m.fit(x, y)
+    fit = O.fit_tpls(x, y, 2)
+    assert len(m.X_factors) == len(shape)
+    assert m.n_iter_ == fit.n_iter
+    assert _normwise(m.X_factors[0], fit.T) <= 1e-8
+    for got, want in zip(m.X_factors[1:], fit.loadings[0]):
+        assert_allclose(np.abs(got), np.abs(want), rtol=0, atol=1e-8)        # (signs: paired flips across modes)
+        assert_allclose(np.linalg.norm(got, axis=0), 1, rtol=1e-12)
+    assert_allclose(m.R2X, fit.r2x[0], rtol=0, atol=1e-9)
+    assert_allclose(m.R2Y, fit.r2y, rtol=0, atol=1e-9)
+    assert_allclose(m.transform(x), m.X_factors[0], rtol=1e-8, atol=1e-10)
+    assert_allclose(m.predict(x[:5]), O.predict(fit, x[:5]), rtol=1e-7, atol=1e-9)
+    xt = x[:6].copy()
+    xt[2, 1, 2, 0, 1, 1] = np.nan                                             # the masked projection at this order too
+    assert _normwise(m.transform(xt), O.transform(fit, xt)) <= 1e-8
