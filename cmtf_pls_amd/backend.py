@@ -426,7 +426,6 @@ class HipBackend:
         small = self.empty(R * R + 2 * (R + 1))                      # coef | ssq: one device -> host copy
         xm, ym = self.empty(P), self.empty(M)
         ints = torch.zeros(R + 1, dtype=torch.int32, device=self.device)    # n_iter | flag
-        # shape check first (no workspace is sized for a shape the kernel refuses)
         ws = self._workspace("fit_small", max(nbytes, 256))
         rc = self.lib.cmtfpls_fit_small_f64(_ptr(X2), _ptr(Y), I, A, B, M, R, float(tol), int(max_iter), _ptr(T), _ptr(U), _ptr(WA), _ptr(WB),
                                             _ptr(Q), _ptr(small), small[R * R:].data_ptr(), _ptr(xm), _ptr(ym), _ptr(ints),

@@ -76,7 +76,7 @@ def split_trailing(shape: Sequence[int]):
 # the first sweep over X, not discovered after a centring pass or 64 components of work.
 MAX_COMPONENTS = 1024          # cmtfpls_normal_solve_ws_f64: the (a+1) x (a+1) normal equations in one workgroup
 MAX_RANK1_SIDE = 4096          # cmtfpls_rank1_f64: min(J, K) of an order-3 block (Gram squaring of the smaller side)
-MAX_TENSOR_MODE = 1024         # cmtfpls_rank1_tensor_f64: every trailing mode of an order-4/5 block
+MAX_TENSOR_MODE = 1024         # cmtfpls_rank1_tensor_f64: every trailing mode of a block of order >= 4
 MAX_ORDER = 8                  # cmtfpls_rank1_tensor_f64 takes cross-covariance tensors of order <= 7
 
 
@@ -278,8 +278,6 @@ class NipalsEngine:
             scores = self._project_one_pass(state, Xs, False, centred=False, nan_flag=flag)
             if scores is not None and int(flag.item()) == 0:
                 return scores
-            if scores is None and state.n_components > 64:
-                return None                                   # (the LDS of project_rows is sized for the usual few components)
             # a missing value somewhere (or a shape the MTTKRP does not take): the reference's masked sequence -- centre,
             # then R times score with the per-row rescale, average the coupled blocks' scores and deflate (tpls.py:128-142,
             # cmtf.py:143-177, missingvals.py:23-38) -- run on every sample in registers, from one read of the uncentred
