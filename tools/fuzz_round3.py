@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Randomised differential checks of the kernels added in round 3 (run on the GPU box; exits non-zero on the first mismatch):
+  mttkrp       every form (k-row on 4x4x4 / 16x16x4 MFMAs, j-block, tile) at random shapes against NumPy
+  project      one-read NaN transform (256- and 1024-thread forms, two coupled blocks) against the oracle's masked sequence
+  fit_small    the one-launch fit against the regular engine
+Usage: python tools/fuzz_round3.py [cases-per-kind] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle as O  # noqa: E402
+from cmtf_pls_amd import ctPLS, tPLS  # noqa: E402
+from cmtf_pls_amd.backend import HipBackend  # noqa: E402
+from cmtf_pls_amd.engine import NipalsEngine  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+be = HipBackend(torch.device("cuda:0"))
+dev = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0").to(dt)
+
+
+def normwise(got, want):
+    scale = np.nanmax(np.abs(want), axis=0, keepdims=True)
+    scale[scale == 0] = 1.0
+    return float(np.nanmax(np.abs(got - want) / (np.abs(want) + scale)))
+
+
+# ---- mttkrp ----------------------------------------------------------------------------------------------------------------
+for case in range(N):
+    dt = [torch.float32, torch.float64][int(rng.integers(2))]
+    A = int(rng.choice([4, 8, 12, 16, 20, 32, 48, 64, 96, 128, 10, 1]))
+    B = int(rng.choice([64, 128, 192, 256, 320, 384, 48, 32, 16, 100]))
+    I = int(rng.integers(1, 70))
+    R = int(rng.integers(1, 18))
+    x = rng.normal(size=(I, A * B))
+    if dt == torch.float32:
+        x = x.astype(np.float32).astype(np.float64)
+    WA, WB = rng.normal(size=(A, R)), rng.normal(size=(B, R))
+    out = be.mttkrp(dev(x, dt), A, B, dev(WA), dev(WB), be.empty(I, R))
+    want = x @ (WA[:, None, :] * WB[None, :, :]).reshape(A * B, R)
+    if out is None:
+        assert (A + B) * 16 * ((R + 15) // 16) * 8 > 152 * 1024, ("mttkrp declined", I, A, B, R)
+        continue
+    err = np.abs(out.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-300)
+    assert err < 1e-11, ("mttkrp", I, A, B, R, dt, err)
+print(f"mttkrp: {N} random cases ok", flush=True)
+
+# ---- one-read NaN projection -----------------------------------------------------------------------------------------------
+def oracle_fit_of(m, coupled):
+    if coupled:
+        loads, means, shapes, T = [list(f[1:]) for f in m.Xs_factors], list(m.Xs_mean), list(m.Xs_shape), m.factor_T
+    else:
+        loads, means, shapes, T = [list(m.X_factors[1:])], [m.X_mean], [m.X_shape], m.X_factors[0]
+    R = m.n_components
+    return O.OracleFit(coupled=coupled, n_components=R, block_shapes=shapes, y_shape=m.Y_shape, T=T, loadings=loads, U=m.Y_factors[0],
+                       Q=m.Y_factors[1], coef=m.coef_, r2x=[np.zeros(R)] * len(loads), r2y=m.R2Y, x_means=means, y_mean=m.Y_mean,
+                       has_miss=[False] * len(loads))
+
+
+calls = {"rows": 0, "rows2": 0}
+for name, key in (("project_rows", "rows"), ("project_rows2", "rows2")):
+    orig = getattr(HipBackend, name)
+
+    def wrapped(self, *a, __orig=orig, __key=key, **k):
+        out = __orig(self, *a, **k)
+        calls[__key] += out is not None
+        return out
+    setattr(HipBackend, name, wrapped)
+
+NipalsEngine.small_fit = False
+for case in range(N // 2):
+    f32 = bool(rng.integers(2))
+    coupled = bool(rng.integers(2))
+    A = int(rng.choice([1, 2, 4, 8, 16, 32, 64, 128, 256, 6]))
+    B = int(rng.choice([8, 16, 32, 64, 128, 256, 512, 1024]))
+    if A * B > (65536 if f32 else 32768):
+        B = 64
+    I, R, M = int(rng.integers(12, 40)), int(rng.integers(1, 7)), int(rng.integers(1, 5))
+    shape = (I, B) if A == 1 else (I, A, B)
+    x, y, cp = O.import_synthetic(shape, M, 3, error=0.2, seed=int(rng.integers(1 << 30)))
+    blocks = [x]
+    if coupled:
+        Bm = int(rng.choice([16, 64, 512, 1024]))
+        blocks.append(cp.factors[0] @ rng.normal(size=(Bm, 3)).T + 0.2 * rng.normal(size=(I, Bm)))
+    if f32:
+        blocks = [b.astype(np.float32).astype(np.float64) for b in blocks]
+        y = y.astype(np.float32).astype(np.float64)
+    dtype = "float32" if f32 else "float64"
+    m = ctPLS(R, dtype=dtype) if coupled else tPLS(R, dtype=dtype)
+    m.fit(blocks if coupled else blocks[0], y, max_iter=15)
+    new = [b[:10].copy() for b in blocks]
+    for b in new:
+        b[rng.random(b.shape) < 0.25] = np.nan
+    new[0][3] = np.nan                                                   # an empty row
+    got = m.transform(new if coupled else new[0])
+    want = O.transform(oracle_fit_of(m, coupled), new if coupled else new[0])
+    assert np.array_equal(np.isnan(got), np.isnan(want)), ("nan pattern", shape, coupled, dtype)
+    ok = ~np.isnan(want).any(axis=1)
+    err = normwise(got[ok], want[ok])
+    assert err < (2e-5 if f32 else 1e-8), ("project", shape, coupled, dtype, R, err)
+print(f"one-read NaN projection: {N // 2} random cases ok ({calls['rows']} through project_rows, {calls['rows2']} through project_rows2, "
+      f"the rest through the passes)", flush=True)
+
+# ---- one-launch small fit ----------------------------------------------------------------------------------------------------
+n_small = 0
+for case in range(N // 3):
+    order3 = bool(rng.integers(2))
+    I = int(rng.integers(8, 120))
+    A, B = (int(rng.integers(2, 20)), int(rng.integers(2, 20))) if order3 else (1, int(rng.integers(2, 200)))
+    M, R = int(rng.integers(1, 6)), int(rng.integers(1, 7))
+    shape = (I, A, B) if order3 else (I, B)
+    x, y, _ = O.import_synthetic(shape, M, 3, error=0.2, seed=int(rng.integers(1 << 30)))
+    NipalsEngine.small_fit = True
+    one = tPLS(R)
+    one.fit(x, y)
+    NipalsEngine.small_fit = False
+    reg = tPLS(R)
+    reg.fit(x, y)
+    n_small += 1
+    assert one.n_iter_ == reg.n_iter_, ("fit_small n_iter", shape, M, R, one.n_iter_, reg.n_iter_)
+    for f, g in zip(one.X_factors + one.Y_factors, reg.X_factors + reg.Y_factors):
+        e = normwise(f, g)
+        assert e < 1e-7, ("fit_small", shape, M, R, e)
+    assert np.abs(np.asarray(one.R2X) - reg.R2X).max() < 1e-10 and np.abs(np.asarray(one.R2Y) - reg.R2Y).max() < 1e-10
+print(f"one-launch small fit: {n_small} random cases ok", flush=True)
