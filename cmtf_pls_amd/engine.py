@@ -338,6 +338,11 @@ class NipalsEngine:
                 for b, (blk, X) in enumerate(zip(state.blocks, Xs)):
                     be.deflate(X.view(I, -1), blk.A, blk.B, t, was[b], wbs[b])
             scores[:, a].copy_(t)
+        if nb > 1 and any(rc is not None for rc in rowcnts):
+            # coupled blocks: a sample whose row is empty in ONE block gets a NaN average (cmtf.py:155,206); the reference's
+            # mask comes from the input, so the NaN-deflated rows of its other blocks give NaN scores from then on, while the
+            # masked score kernels read those entries as missing: restore the reference's outcome on the I x R result
+            scores.masked_fill_(torch.isnan(scores).cumsum(dim=1) > 0, float("nan"))
         return scores
 
     def _kr_operands(self, blk: BlockState, R: int):

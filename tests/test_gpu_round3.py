@@ -319,3 +319,25 @@ def test_fit_of_order_6_and_7_tensors(api, shape, algorithm):
     xt = x[:6].copy()
     xt[2, 1, 2, 0, 1, 1] = np.nan                                             # the masked projection at this order too
     assert _normwise(m.transform(xt), O.transform(fit, xt)) <= 1e-8
+
+
+def test_three_coupled_blocks_with_an_empty_row_keep_the_references_nan_semantics(api):
+    """Three coupled blocks take the sequential passes (the one-read kernel holds two).  A sample whose row is empty in one
+    block has a NaN average score at step 0 (cmtf.py:206); the reference's input-derived mask then makes every later score of
+    that sample NaN as well -- not the finite values a mask re-read from the NaN-deflated rows would give."""
+    rng = np.random.default_rng(23)
+    lat = rng.normal(size=(80, 3))
+    xs = [np.einsum("ir,jr,kr->ijk", lat, rng.normal(size=(6, 3)), rng.normal(size=(5, 3))) + 0.1 * rng.normal(size=(80, 6, 5)),
+          lat @ rng.normal(size=(3, 12)) + 0.1 * rng.normal(size=(80, 12)),
+          lat @ rng.normal(size=(3, 7)) + 0.1 * rng.normal(size=(80, 7))]
+    y = lat @ rng.normal(size=(3, 2)) + 0.1 * rng.normal(size=(80, 2))
+    m = api.ctPLS(3)
+    m.fit(xs, y)
+    new = [b[:12].copy() for b in xs]
+    new[0][rng.random(new[0].shape) < 0.2] = np.nan
+    new[1][4] = np.nan                                            # sample 4: no observation in the second block
+    got = m.transform(new)
+    want = O.transform(_oracle_fit_of(m, True), new)
+    assert np.all(np.isnan(want[4])) and np.all(np.isnan(got[4]))
+    keep = np.arange(12) != 4
+    assert _normwise(got[keep], want[keep]) <= 1e-9
