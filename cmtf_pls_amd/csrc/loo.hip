@@ -15,6 +15,8 @@
 // exact pass with Z, sign rule on the last mode), run inside the workgroup with G in LDS.
 // Limits (the caller falls back to one refit per fold on the regular engine otherwise): X of order 2 or 3 without
 // missing values, min(A, B) <= 64, M <= 64, R <= 16, and the per-workgroup vectors must fit 150 KB of LDS.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cmtfpls {
@@ -150,6 +152,80 @@ __device__ void loo_rank1(const double* Z, int A, int B, double* wA, double* wB,
   __syncthreads();
 }
 
+// The same extraction for n = min(A, B) <= 8 and k = max(A, B) <= 64 (BASELINE configs[0]: 10 x 8), entirely inside ONE
+// wavefront: the n x n Gram matrix is one entry per lane (lane = 8 i + j), a squaring is 16 lane permutes and 8 FMAs per lane,
+// trace and Frobenius norm are butterfly sums -- no workgroup barrier anywhere (the block form above spends ~5 barriers of a
+// 16-wavefront workgroup per squaring: 25 of the 46 us of a one-workgroup iteration).  Same seed rule (dominant diagonal entry,
+// first index on ties), same exact pass with Z, same sign rule.  All threads call it; wavefront 0 works.
+__device__ void loo_rank1_wave(const double* Z, int A, int B, double* wA, double* wB) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const bool rowsA = A <= B;
+    const int n = rowsA ? A : B, k = rowsA ? B : A;
+#define LOO_M(i, l) (rowsA ? Z[(i) * B + (l)] : Z[(l) * B + (i)])
+    const int i = tid >> 3, j = tid & 7;
+    const bool in = (i < n && j < n);
+    double g = 0.0;
+    if (in)
+      for (int l = 0; l < k; ++l) g = fma(LOO_M(i, l), LOO_M(j, l), g);
+    for (int step = 0; step < 64; ++step) {
+      const double tr = wave_sum((in && i == j) ? g : 0.0), fro = wave_sum(g * g);
+      if (!(tr > 0.0) || !isfinite(tr) || fro / (tr * tr) >= 1.0 - 1e-13) break;     // uniform: wave_sum gives every lane the same bits
+      int e;
+      frexp(tr, &e);
+      const double sc = ldexp(1.0, -e), sc2 = sc * sc;
+      double s2 = 0.0;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) s2 = fma(__shfl(g, 8 * i + l, kWave), __shfl(g, 8 * j + l, kWave), s2);   // G symmetric: row j = column j
+      g = in ? s2 * sc2 : 0.0;
+    }
+    // dominant diagonal entry (first index on ties)
+    double bv = (in && i == j) ? g : -1.0;
+    int bi = i;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      const double ov = __shfl_xor(bv, m, kWave);
+      const int oi = __shfl_xor(bi, m, kWave);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    // seed = row bi of G, normalised: lane l < n holds seed[l]
+    double seed = __shfl(g, 8 * bi + (tid & 7), kWave);
+    if (tid >= n) seed = 0.0;
+    const double snrm = sqrt(wave_sum(seed * seed));
+    seed = seed / snrm;
+    // y = M^T seed (lane l < k holds y[l]);  x = M y (lane i < n holds x[i])
+    double y = 0.0;
+    for (int ii = 0; ii < n; ++ii) {
+      const double sv = __shfl(seed, ii, kWave);
+      if (tid < k) y = fma(LOO_M(ii, tid), sv, y);
+    }
+    double x = 0.0;
+    for (int l = 0; l < k; ++l) {
+      const double yv = __shfl(y, l, kWave);
+      if (tid < n) x = fma(LOO_M(tid, l), yv, x);
+    }
+#undef LOO_M
+    const double nx = sqrt(wave_sum(tid < n ? x * x : 0.0)), ny = sqrt(wave_sum(tid < k ? y * y : 0.0));
+    // sign rule on the LAST mode's vector wB: its largest-|.| entry is positive (first index on ties)
+    const double vb = rowsA ? y : x;
+    const int nb = rowsA ? k : n;
+    double av = (tid < nb) ? fabs(vb) : -1.0;
+    int ai = tid;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      const double ov = __shfl_xor(av, m, kWave);
+      const int oi = __shfl_xor(ai, m, kWave);
+      if (ov > av || (ov == av && oi < ai)) { av = ov; ai = oi; }
+    }
+    const double sgn = (__shfl(vb, ai, kWave) < 0.0) ? -1.0 : 1.0;
+    double* ox = rowsA ? wA : wB;
+    double* oy = rowsA ? wB : wA;
+    if (tid < n) ox[tid] = sgn * (x / nx);
+    if (tid < k) oy[tid] = sgn * (y / ny);
+  }
+  __syncthreads();
+}
+
 // NT = 256 for the leave-one-out launch (one workgroup per fold, the folds side by side on the CUs); NT = 1024 for the
 // whole fit, where the one workgroup is all the parallelism there is
 template <int NT>
@@ -282,7 +358,8 @@ __global__ __launch_bounds__(NT) void loo_tpls_kernel(LooArgs a) {
         if (tid == 0) wA[0] = 1.0;
         __syncthreads();
       } else {
-        loo_rank1<NT>(Z, A, B, wA, wB, G0, G1, xs, ys, red, ired);                         // tpls.py:86-88
+        if (n <= 8 && k <= 64) loo_rank1_wave(Z, A, B, wA, wB);                          // tpls.py:86-88, inside one wavefront
+        else loo_rank1<NT>(Z, A, B, wA, wB, G0, G1, xs, ys, red, ired);
       }
       // t = X x_1 wA x_2 wB (tpls.py:97-99): one wavefront per row
       for (int r = wv; r < I; r += kLooThreads / 64) {
@@ -513,6 +590,13 @@ int cmtfpls_fit_small_f64(const double* X, const double* Y, int I, int A, int B,
   a.lds_xy_offset = xy_off;
   a.U_out = U; a.WA_out = WA; a.WB_out = WB; a.Q_out = Q; a.coef_out = coef; a.ssq_out = ssq; a.xmean_out = x_mean; a.ymean_out = y_mean;
   a.flag_out = flag;
+  // (tuning hook: CMTFPLS_FIT_SMALL_NT=256 runs the 256-thread instance)
+  const char* nt_env = getenv("CMTFPLS_FIT_SMALL_NT");
+  if (nt_env && atoi(nt_env) == 256) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(loo_tpls_kernel<256>, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
+    return check_launch("fit_small");
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(loo_tpls_kernel<1024>, dim3(1), dim3(1024), lds, (hipStream_t)stream, a);
   return check_launch("fit_small");
