@@ -225,6 +225,91 @@ __global__ __launch_bounds__(256) void mttkrp_mixed_kernel(const float* __restri
   }
 }
 
+// The k-row form of mttkrp.hip (round 3: the matrix cores contract over the j-rows with the plain loading WA[j, r] as B operand,
+// fully coalesced loads, WB folded into the accumulators afterwards) on the f32 matrix cores: X exact, WA[j, r] rounded once to
+// f32, f32 accumulation inside a chain of at most 64 j-steps (256 terms), every chain multiplied by the f64 WB[k, r] into one f64
+// double per lane.  Shapes as mttkrp_kj_kernel<float, NL>: B % (NL * 64) == 0, A % (32 / NL) == 0, R <= 16.
+template <int NL>
+__global__ __launch_bounds__(256) void mttkrp_kj_mixed_kernel(const float* __restrict__ X, int64_t I, int A, int B,
+                                                              const double* __restrict__ WA, const double* __restrict__ WB, int R,
+                                                              double* __restrict__ out, int ldo) {
+  constexpr int V = 4, RP = 16, CHJ = 8 / NL, KP = NL * 16 * V;
+  constexpr int FLUSH = 64 / CHJ;          // chunks per f32 chain (64 j-steps = 256 terms)
+  extern __shared__ double lds[];          // sB[B][16] f64, then sA[A][16] as f32
+  double* sB = lds;
+  float* sA = reinterpret_cast<float*>(lds + (size_t)B * RP);
+  for (int idx = threadIdx.x; idx < A * RP; idx += 256) { const int j = idx / RP, r = idx % RP; sA[idx] = (r < R) ? (float)WA[(int64_t)j * R + r] : 0.f; }
+  for (int idx = threadIdx.x; idx < B * RP; idx += 256) { const int k = idx / RP, r = idx % RP; sB[idx] = (r < R) ? WB[(int64_t)k * R + r] : 0.0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kk = lane & 15, jq = lane >> 4;
+  const int64_t P = (int64_t)A * B;
+  const int npass = B / KP, cpp = A / (4 * CHJ);
+  const int nchunks = npass * cpp, npairs = nchunks / 2;
+  const int64_t istep = (int64_t)gridDim.x * 4;
+  using XV = Pack<float, V>;
+  XV b0[CHJ][NL], b1[CHJ][NL];
+  auto load = [&](XV (&buf)[CHJ][NL], const float* __restrict__ xs, int q) {
+    const int ps = q / cpp, c = q - ps * cpp;
+    const float* __restrict__ xp = xs + (int64_t)(c * CHJ * 4) * B + ps * KP;
+#pragma unroll
+    for (int h = 0; h < CHJ; ++h)
+#pragma unroll
+      for (int n = 0; n < NL; ++n) buf[h][n] = ld_stream(reinterpret_cast<const XV*>(xp + (int64_t)(h * 4) * B + n * 16 * V));
+  };
+  int64_t i = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t lane_off = (int64_t)jq * B + V * kk;
+  if (i < I) load(b0, X + i * P + lane_off, 0);
+  for (; i < I; i += istep) {
+    const float* __restrict__ xs = X + i * P + lane_off;
+    const float* __restrict__ xs_next = X + ((i + istep < I) ? i + istep : i) * P + lane_off;
+    double s = 0.0;
+    f4_t acc[NL][V];
+#pragma unroll
+    for (int n = 0; n < NL; ++n)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[n][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](XV (&buf)[CHJ][NL], int q) {
+      const int ps = q / cpp, c = q - ps * cpp;
+      const float* __restrict__ sa = sA + (size_t)(c * CHJ * 4 + jq) * RP + kk;
+#pragma unroll
+      for (int h = 0; h < CHJ; ++h) {
+        const float wa = sa[(size_t)(h * 4) * RP];
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[n][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[h][n].e[e], wa, acc[n][e], 0, 0, 0);
+      }
+      if (c == cpp - 1 || (c % FLUSH) == FLUSH - 1) {     // end of an f32 chain / of the pass: fold WB in (f64), fresh accumulators
+        const double* __restrict__ sb = sB + (size_t)(ps * KP) * RP + kk;
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s = fma(sb[(size_t)(n * 16 * V + V * (4 * jq + g) + e) * RP], (double)acc[n][e][g], s);   // f32 D layout: row 4 (l >> 4) + g
+            acc[n][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+    };
+    for (int t = 0; t < npairs; ++t) {
+      const int q = 2 * t;
+      load(b1, xs, q + 1);
+      compute(b0, q);
+      const bool more = (q + 2 < nchunks);
+      load(b0, more ? xs : xs_next, more ? q + 2 : 0);
+      compute(b1, q + 1);
+    }
+    if (nchunks & 1) {
+      compute(b0, nchunks - 1);
+      load(b0, xs_next, 0);
+    }
+    s += __shfl_xor(s, 16, kWave);
+    s += __shfl_xor(s, 32, kWave);
+    if (jq == 0 && kk < R) out[i * ldo + kk] = s;
+  }
+}
+
 }  // namespace cmtfpls
 
 using namespace cmtfpls;
@@ -264,10 +349,26 @@ int cmtfpls_mttkrp_f32_mixed(const float* X, int64_t I, int A, int B, const doub
   const size_t lds = (size_t)(A + B) * 16 * rt * sizeof(double);
   if (lds > 96 * 1024) { set_error("mttkrp_mixed: loadings exceed LDS"); return CMTFPLS_EUNSUPPORTED; }
   const bool vec = (B % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (R <= 16 && vec) {
+    // the k-row form (coalesced loads, WA as the plain B operand): 128-column passes, or 64
+    const size_t lds_kj = (size_t)B * 16 * sizeof(double) + (size_t)A * 16 * sizeof(float);
+    int gk = (int)((I + 3) / 4);
+    if (gk > 2048) gk = 2048;
+    if (lds_kj <= 64 * 1024) {
+      if (B % 128 == 0 && A % 16 == 0) {
+        hipLaunchKernelGGL((mttkrp_kj_mixed_kernel<2>), dim3(gk), dim3(256), lds_kj, st, X, I, A, B, WA, WB, R, out, ldo);
+        return check_launch("mttkrp_mixed");
+      }
+      if (B % 64 == 0 && A % 32 == 0) {
+        hipLaunchKernelGGL((mttkrp_kj_mixed_kernel<1>), dim3(gk), dim3(256), lds_kj, st, X, I, A, B, WA, WB, R, out, ldo);
+        return check_launch("mttkrp_mixed");
+      }
+    }
+  }
   const int64_t ngroups = (I + 15) / 16;
   int grid = (int)((ngroups + 3) / 4);
   if (grid > 2048) grid = 2048;
-  hipStream_t st = (hipStream_t)stream;
 #define ML(VC, RTT) hipLaunchKernelGGL((mttkrp_mixed_kernel<VC, RTT>), dim3(grid), dim3(256), lds, st, X, I, A, B, WA, WB, R, out, ldo)
   if (vec) { if (rt == 1) ML(true, 1); else ML(true, 2); }
   else     { if (rt == 1) ML(false, 1); else ML(false, 2); }

@@ -46,7 +46,9 @@ def test_xcov_mixed(be, shape, M, masked):
 
 
 @pytest.mark.parametrize("shape,R", [((37, 10, 8), 3), ((100, 38, 65), 8), ((64, 1, 20), 5), ((50, 128, 128), 10),
-                                     ((70, 12, 8), 17), ((300, 16, 16), 32)])
+                                     ((70, 12, 8), 17), ((300, 16, 16), 32),
+                                     # round 3, the k-row form: 128- and 64-column passes, two passes, more than one f32 chain (A > 256)
+                                     ((41, 128, 128), 10), ((23, 32, 64), 7), ((19, 16, 256), 16), ((9, 272, 128), 5)])
 def test_mttkrp_mixed(be, shape, R):
     rng = np.random.default_rng(62)
     I, A, B = shape
