@@ -802,6 +802,48 @@ __global__ __launch_bounds__(kSweepThreads) __attribute__((amdgpu_waves_per_eu(5
   }
 }
 
+// score of a FEW LONG rows (I <= 64 rows of >= 8192 elements: S = Y^T X_(0) with its M rows inside the cross-covariance
+// loop, a handful of new samples in transform): the wavefront-per-row kernel above keeps I wavefronts busy -- 16 for the
+// 16 x 16384 S of BASELINE configs[1], 13 us per call -- so here a 1024-thread workgroup takes one row: every thread its vectors
+// at stride 1024 V, per-lane sequential sum, butterfly wave sum, the 16 wavefronts added in index order.
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(1024) void score_fewrows_kernel(const T* __restrict__ X, int A, int B, const double* __restrict__ wA,
+                                                            const double* __restrict__ wB, const double* __restrict__ rowcnt,
+                                                            double* __restrict__ t) {
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  const double* sA = lds;
+  const double* sB = lds + ((A + 1) & ~1);
+  stage_loadings(lds, lds + ((A + 1) & ~1), wA, wB, A, B);
+  constexpr int V = VecOf<T>::N;
+  using VT = Pack<T, V>;
+  const int64_t P = (int64_t)A * B;
+  const int64_t step = (int64_t)1024 * V;
+  const int64_t row = blockIdx.x;
+  const T* __restrict__ xr = X + row * P;
+  KronWalk w((int64_t)threadIdx.x * V, step, B);
+  double acc = 0.0;
+  int64_t c = (int64_t)threadIdx.x * V;
+  constexpr int UN = 4;
+  for (; c + (UN - 1) * step < P; c += UN * step) {
+    VT x[UN];
+#pragma unroll
+    for (int s = 0; s < UN; ++s) x[s] = ld_stream(reinterpret_cast<const VT*>(xr + c + s * step));
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x[s], sB + w.k), acc);
+      w.next();
+    }
+  }
+  for (; c < P; c += step) {
+    const VT x = ld_stream(reinterpret_cast<const VT*>(xr + c));
+    acc = fma(sA[w.j], dot_pack<T, V, MASKED>(x, sB + w.k), acc);
+    w.next();
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) t[row] = MASKED ? acc / rowcnt[row] * (double)P : acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // deflate: X[i,c] -= t[i] wA[c/B] wB[c%B]  (+ sum of squares of what is left)   wavefront per row
 // ------------------------------------------------------------------------------------------
@@ -1260,6 +1302,11 @@ static int run_score(const T* X, int64_t I, int A, int B, const double* wA, cons
   const bool gl = lds > kMaxLoadingsLds;               // loadings longer than the LDS: read them through L2
   if (gl) lds = 0;
   const bool v = vec_ok(X, B), m = rowcnt != nullptr;
+  if (!gram && v && !gl && I <= 64 && (int64_t)A * B >= 8192) {      // a few long rows: one 1024-thread workgroup per row
+    if (m) hipLaunchKernelGGL((score_fewrows_kernel<T, true>), dim3((unsigned)I), dim3(1024), lds, st, X, A, B, wA, wB, rowcnt, t);
+    else hipLaunchKernelGGL((score_fewrows_kernel<T, false>), dim3((unsigned)I), dim3(1024), lds, st, X, A, B, wA, wB, rowcnt, t);
+    return check_launch("score");
+  }
   const dim3 g(kSweepBlocks), b(kSweepThreads);
 #define LAUNCH(MS, V, G) do { if (gl) hipLaunchKernelGGL((score_kernel<T, MS, V, G, true>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart); \
     else hipLaunchKernelGGL((score_kernel<T, MS, V, G, false>), g, b, lds, st, X, I, A, B, wA, wB, rowcnt, t, Y, ldy, M, qpart); } while (0)
