@@ -16,10 +16,18 @@ region.  Workload: BASELINE.json configs[1] (X 65536x128x128 f32, Y 65536x16, R=
 the same X is row-sharded over the N ranks, as the metric is quoted ("iters/sec on X 65536x128x128 at
 1/2/4/8 GPU"); per iteration the ranks all-reduce Z (J*K doubles) and Y^T t (M doubles).
 
+Timing (round 3): W warm-up steps, then ``--repeats`` (default 5) windows of EXACTLY K steps each, every window bracketed by a
+barrier + ``torch.cuda.synchronize()`` on both sides and reduced with MAX over ranks; ``value`` = K / the MEDIAN window
+(``value_min`` / ``value_max`` = the slowest / fastest window).  At N = 1 with the default workload the line also carries
+``north_star``: BASELINE configs[4] (X 262144x256x256 f32 = 68.7 GB, Y 262144x32) formed on the device after the cfg-2 legs,
+direct iterations under graph replay and the component's deflation sweeps (skipped when less than 150 GB of HBM are free).
+
 Rank 0 prints ONE JSON line; ``roofline`` is the dominant kernel (the mode-0 contraction launch) from HIP
 events on the launch stream inside the timed region, against the 8 TB/s spec peak AND against streaming
 ceilings measured in the same run (``peak_measured_read`` / ``peak_measured_rmw``: plain float4
-read-only / read-modify-write kernels of libcmtfpls over an X-sized buffer); ``cpu_baseline`` is the
+read-only / read-modify-write kernels of libcmtfpls over an X-sized buffer); ``roofline.traffic`` = HBM bytes per launch from
+profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command), quoted only while the kernel it names is in the
+running library and the sources it was compiled from are unchanged (else null, with the reason); ``cpu_baseline`` is the
 NumPy oracle's inner loop timed on this host on a row sample (rank 0, N=1 only).  ``fit`` is the sec-to-fit leg: whole
 fits (default tol / max_iter, preprocessing included) through the direct loop, the cross-covariance form and its
 f32-MFMA variant, each run twice (``first_call_seconds``, ``seconds``).
