@@ -184,6 +184,17 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_kr_axpy_f64(_ptr(v), A, B, _ptr(WA), _ptr(WB), WA.shape[1], int(k), _ptr(coef), self._stream()), "kr_axpy")
         return v
 
+    def axpy_scalar(self, y: torch.Tensor, a: torch.Tensor, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """y -= a[0] * x (x = None: ones); a is a one-element device tensor."""
+        assert y.is_contiguous() and y.dtype == torch.float64 and a.numel() >= 1 and (x is None or (x.is_contiguous() and x.numel() == y.numel()))
+        _lib.check(self.lib.cmtfpls_axpy_scalar_f64(_ptr(y), y.numel(), _ptr(a), _ptr(x), self._stream()), "axpy_scalar")
+        return y
+
+    def total(self, v: torch.Tensor) -> torch.Tensor:
+        """Sum of a contiguous f64 vector as a one-element device tensor (fixed-order, one workgroup)."""
+        assert v.is_contiguous() and v.dtype == torch.float64
+        return self._close_partials(v)
+
     def quadform(self, G: torch.Tensor, q: torch.Tensor, q_old: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.check(self.lib.cmtfpls_quadform_f64(_ptr(G), G.shape[0], _ptr(q), _ptr(q_old), _ptr(out), self._stream()), "quadform")
         return out

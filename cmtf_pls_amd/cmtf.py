@@ -38,14 +38,15 @@ class ctPLS(_EstimatorBase):
         self.Xs_dim = [X.ndim for X in Xs]
         self.Xs_shape = [tuple(X.shape) for X in Xs]
         self.Y_shape = tuple(Y2.shape)
-        Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=self._copy_X) for X in Xs]
+        Xd = [to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=False) for X in Xs]    # cloned by the engine if written
         Yd = to_device_copy(Y2, torch.float64, dev)
         def notice(blocks):                                               # during preprocess, before the loop: cmtf.py:78-79
             if any(b.has_miss for b in blocks):
                 print("At least one X has missing values")
 
         st = eng.fit(Xd, Yd, self.n_components, tol, max_iter, coupled=True, verbose=verbose, algorithm=self._algorithm,
-                     use_graphs=self._graphs, mixed=self._mixed, on_preprocessed=notice)
+                     use_graphs=self._graphs, mixed=self._mixed, on_preprocessed=notice,
+                     owned=[(xd is not X) or not self._copy_X for xd, X in zip(Xd, Xs)])
         del Xd
         self._state = st
         self.factor_T = st.T.cpu().numpy()

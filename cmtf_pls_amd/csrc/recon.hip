@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kSweepThreads) void recon_r2_kernel(const T* __rest
 void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st);
 
 static void recon_r2_plan(int64_t I, int64_t P, int V, int* col_tiles, int* row_blocks, int64_t* rpb) {
-  *col_tiles = (int)((P / V + kSweepThreads - 1) / kSweepThreads);
+  *col_tiles = (int)(((P + V - 1) / V + kSweepThreads - 1) / kSweepThreads);      // (>= 1 for P >= 1: a block of fewer columns than a
+  if (*col_tiles < 1) *col_tiles = 1;                                             //  vector made this 0 and the next line divide by it)
   int64_t want = (2048 + *col_tiles - 1) / *col_tiles;
   *rpb = (I + want - 1) / want;
   if (*rpb < 8) *rpb = 8;

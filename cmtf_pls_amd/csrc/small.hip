@@ -238,6 +238,14 @@ __global__ __launch_bounds__(256) void s_downdate_kernel(double* __restrict__ S,
   }
 }
 
+// y[i] -= a[0] * (x ? x[i] : 1): the two rank-one corrections of the cross-covariance loop on an UNCENTRED X (round 3):
+//   X_c w = X w - (mean^T w) 1   (a scalar shift of the I scores),   X_c^T yhat = X^T yhat - (1^T yhat) mean   (P entries).
+__global__ __launch_bounds__(256) void axpy_scalar_kernel(double* __restrict__ y, int64_t n, const double* __restrict__ a,
+                                                         const double* __restrict__ x) {
+  const double av = a[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = fma(-av, x ? x[i] : 1.0, y[i]);
+}
+
 // v[c] -= sum_{j < k} coef[j] * WA[(c / B) * ld + j] * WB[(c % B) * ld + j]: a rank-k correction in Khatri-Rao form, the
 // Khatri-Rao product never materialised.  Used by the xcov algorithm when X is NOT deflated in place: with
 // X_a = X_0 - sum_{j<a} t_j w_j^T the contraction the S down-date needs is X_{a+1}^T yhat = X_0^T yhat - sum_{j<=a} w_j (t_j^T yhat).
@@ -355,6 +363,14 @@ int cmtfpls_s_downdate_f64(double* S, int M, int A, int B, const double* ya, con
   const int64_t P = (int64_t)A * B;
   hipLaunchKernelGGL(s_downdate_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, M, P, B, ya, wA, wB, q, v);
   return check_launch("s_downdate");
+}
+
+int cmtfpls_axpy_scalar_f64(double* y, int64_t n, const double* a, const double* x, void* stream) {
+  if (!y || !a || n <= 0) { set_error("axpy_scalar: bad argument"); return CMTFPLS_EINVAL; }
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(axpy_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, n, a, x);
+  return check_launch("axpy_scalar");
 }
 
 int cmtfpls_kr_axpy_f64(double* v, int A, int B, const double* WA, const double* WB, int ld, int k, const double* coef, void* stream) {

@@ -131,6 +131,9 @@ class NipalsEngine:
     # algorithm="xcov" on blocks without missing values: never deflate X in place (two reads per component instead of a
     # read and a read + write, see FitRun._finish_xcov_nowrite); False keeps the deflating form (tests compare the two)
     xcov_nowrite = True
+    # ... and, when X is never written anyway, do not centre it either (round 3): the fit runs on the caller's UNCENTRED tensor --
+    # no centring pass, no private copy -- with two rank-one corrections (FitRun._finish_xcov_nowrite); False keeps the centred copy
+    xcov_raw = True
 
     def __init__(self, backend, comm=None):
         self.be = backend
@@ -146,8 +149,10 @@ class NipalsEngine:
         return contextlib.nullcontext()
 
     # ------------------------------------------------------------------------------------
-    def _prepare_block(self, X: torch.Tensor, n_total: int) -> BlockState:
-        """tpls.py:61-71: NaN statistics, nanmean over samples, centring (in place on the copy)."""
+    def _prepare_block(self, X: torch.Tensor, n_total: int, defer_centring: bool = False) -> BlockState:
+        """tpls.py:61-71: NaN statistics, nanmean over samples, centring (in place on the copy).
+        defer_centring: only the statistics (one read of X, nothing written); `_centre_block` completes the block later --
+        in place, or never when the fit can run on the uncentred tensor (FitRun, algorithm="xcov")."""
         be, comm = self.be, self.comm
         I = X.shape[0]
         X2 = X.view(I, -1)
@@ -158,10 +163,29 @@ class NipalsEngine:
         comm.allreduce(colcnt)
         mean = colsum / colcnt                                  # nanmean; 0/0 -> NaN like numpy
         has_miss = bool((colcnt.sum() < float(n_total) * P - 0.5).item())
-        rowcnt, ssq0 = be.center(X2, mean, has_miss)
-        comm.allreduce(ssq0)
-        return BlockState(shape=tuple(X.shape), A=A, B=B, mean=mean, has_miss=has_miss,
-                          colcnt=colcnt if has_miss else None, rowcnt=rowcnt, ssq0=float(ssq0.item()), dtype=X.dtype)
+        blk = BlockState(shape=tuple(X.shape), A=A, B=B, mean=mean, has_miss=has_miss,
+                         colcnt=colcnt if has_miss else None, rowcnt=None, ssq0=float("nan"), dtype=X.dtype)
+        if not defer_centring:
+            self._centre_block(blk, X)
+        return blk
+
+    def _centre_block(self, blk: BlockState, X: torch.Tensor) -> None:
+        """X -= X_mean in place (tpls.py:71), the per-row observation counts and |X_c|^2 (the R2X denominator)."""
+        rowcnt, ssq0 = self.be.center(X.view(X.shape[0], -1), blk.mean, blk.has_miss)
+        self.comm.allreduce(ssq0)
+        blk.rowcnt, blk.ssq0 = rowcnt, float(ssq0.item())
+
+    def _ssq_uncentred(self, blk: BlockState, X: torch.Tensor) -> bool:
+        """|X - X_mean|^2 from ONE READ of the uncentred block, nothing written (cmtfpls_recon_r2_* against an all-zero
+        reconstruction); False when the backend / shape has no such form."""
+        be = self.be
+        I = X.shape[0]
+        z = lambda n: be.zeros(n, 1)
+        out = be.recon_r2(X.view(I, -1), z(I), z(blk.A), z(blk.B), blk.mean) if hasattr(be, "recon_r2") else None
+        if out is None:
+            return False
+        blk.ssq0 = float(self.comm.allreduce(out)[1].item())
+        return True
 
     def _rank1(self, blk: BlockState, Z: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
                info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None,
@@ -194,14 +218,15 @@ class NipalsEngine:
 
     # ------------------------------------------------------------------------------------
     def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool,
-              algorithm: str = "direct") -> "FitRun":
-        """Preprocess (centre in place) and allocate the per-fit buffers; see FitRun."""
+              algorithm: str = "direct", owned: Optional[List[bool]] = None) -> "FitRun":
+        """Preprocess (centre in place) and allocate the per-fit buffers; see FitRun.  owned[b] = False: block b is the
+        CALLER's tensor -- it is cloned before anything writes it, and not at all when the fit only reads it."""
         with self.device_ctx():
-            return FitRun(self, Xs, Y, n_components, coupled, algorithm)
+            return FitRun(self, Xs, Y, n_components, coupled, algorithm, owned)
 
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
             coupled: bool, verbose: int = 0, algorithm: str = "direct", use_graphs: bool = False,
-            mixed: bool = False, on_preprocessed=None) -> FitState:
+            mixed: bool = False, on_preprocessed=None, owned: Optional[List[bool]] = None) -> FitState:
         """Xs: device copies (will be centred and deflated in place); Y: (I_local, M) f64 copy.
         algorithm: "direct" = the reference's loop (two X reads per iteration); "xcov" = the same
         iteration re-associated through S = X_(0)^T Y (one X read + one read/write per component)."""
@@ -209,7 +234,7 @@ class NipalsEngine:
             small = self._fit_small(Xs, Y, n_components, tol, max_iter, coupled, verbose, on_preprocessed)
             if small is not None:
                 return small
-            run = self.begin(Xs, Y, n_components, coupled, algorithm)
+            run = self.begin(Xs, Y, n_components, coupled, algorithm, owned)
             if on_preprocessed is not None:                          # the estimators print their missing-value notice
                 on_preprocessed(run.blocks)                          # here, where the reference does (tpls.py:62-63)
             run.tol = tol                                            # also handed to parafac (tpls.py:86)
@@ -436,8 +461,10 @@ class FitRun:
     ``iterate`` directly so that the timed step IS the product's iteration."""
 
     def __init__(self, eng: NipalsEngine, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool,
-                 algorithm: str = "direct"):
+                 algorithm: str = "direct", owned: Optional[List[bool]] = None):
         be, comm = eng.be, eng.comm
+        Xs = list(Xs)
+        owned = [True] * len(Xs) if owned is None else list(owned)
         if algorithm not in ("direct", "xcov"):
             raise ValueError("algorithm must be 'direct' or 'xcov'")
         if algorithm == "xcov" and Y.shape[1] > 64:
@@ -451,7 +478,23 @@ class FitRun:
         n_tot = torch.tensor([float(I)], dtype=torch.float64, device=Y.device)
         comm.allreduce(n_tot)
         self.n_total = int(round(float(n_tot.item())))
-        self.blocks = [eng._prepare_block(X, self.n_total) for X in Xs]
+        # algorithm="xcov" on blocks without missing values reads X and never writes it (_finish_xcov_nowrite): then it need not be
+        # centred either.  The statistics pass decides: raw = every block NaN-free and every kernel of that path present.
+        want_raw = (algorithm == "xcov" and bool(getattr(eng, "xcov_raw", False)) and bool(getattr(eng, "xcov_nowrite", False))
+                    and n_components <= 64
+                    and all(hasattr(be, f) for f in ("axpy_scalar", "total", "recon_r2", "s_downdate", "deflate_contract_yq", "kr_axpy")))
+        if not want_raw:
+            for b in range(len(Xs)):
+                if not owned[b]:
+                    Xs[b] = Xs[b].clone()                        # the fit centres and deflates in place: never the caller's tensor
+        self.blocks = [eng._prepare_block(X, self.n_total, defer_centring=want_raw) for X in Xs]
+        self.raw = (want_raw and not any(blk.has_miss for blk in self.blocks)
+                    and all(eng._ssq_uncentred(blk, X) for blk, X in zip(self.blocks, Xs)))
+        if want_raw and not self.raw:                            # missing values (or no read-only norm): the deflating form after all
+            for b, blk in enumerate(self.blocks):
+                if not owned[b]:
+                    Xs[b] = Xs[b].clone()
+                eng._centre_block(blk, Xs[b])
         self.X2 = [X.view(I, -1) for X in Xs]
         ysum, ycnt = be.colstats(Y)
         comm.allreduce(ysum)
@@ -538,6 +581,10 @@ class FitRun:
                              and all(hasattr(be, f) for f in ("s_downdate", "deflate_contract_yq")))
             self._s_ready = False
             self._nowrite = False
+            if self.raw:
+                self.zM = be.zeros(M)
+                self.zA = [be.zeros(blk.A) for blk in self.blocks]
+                self.zB = [be.zeros(blk.B) for blk in self.blocks]
             if self._s_carry:
                 self.yhat = be.empty(I, 1)
                 self.one = be.empty(1)
@@ -550,6 +597,7 @@ class FitRun:
                     self.dot_log = be.zeros(R, 1 + len(self.blocks))
                     self.Gw = be.empty(R * R)
                     self._G_last = None
+            assert self._nowrite or not self.raw, "an uncentred X needs the form of the loop that never writes it"
 
     def start_component(self, a: int) -> None:
         self._executed = 0
@@ -569,6 +617,11 @@ class FitRun:
                 break                                             # S was down-dated by the previous finish_component
             be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b], mixed=self.mixed)
             comm.allreduce(self.S[b])
+            if self.raw:
+                # X is uncentred: X_c^T Y = X^T Y - mean (1^T Y)^T; the centred Y sums to ~1e-13 per column, not to exactly 0
+                ysum, _ = be.colstats(self.Y)
+                comm.allreduce(ysum)
+                be.s_downdate(self.S[b], blk.A, blk.B, self.zM, self.zA[b], self.zB[b], ysum, blk.mean)
             if blk.has_miss:
                 torch.mul(self.Y, self.rowscale[b][:, None], out=self.Yw)
                 be.xcov(self.X2[b], self.Yw, True, out=self.S2[b], mixed=self.mixed)
@@ -1016,6 +1069,9 @@ class FitRun:
         self._store_loadings(a)
         for b, blk in enumerate(self.blocks):
             be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Ts[b])       # X_0 w_a
+            if self.raw:                                                         # uncentred X: X_c w = X w - (mean^T w) 1
+                mw = be.score(blk.mean.view(1, -1), blk.A, blk.B, self.wA[b], self.wB[b], None, be.empty(1))
+                be.axpy_scalar(self.Ts[b], mw)
             if a > 0:
                 for m, L in enumerate(blk.loadings):                             # Gram of a Khatri-Rao product =
                     be.kr_gram(L, self.Gw, first=(m == 0))                       # Hadamard product of the mode Grams
@@ -1046,6 +1102,8 @@ class FitRun:
                 WA, WB = self.eng._kr_operands(blk, R)                           # columns <= a: the components so far
                 be.mode0_contract(self.X2[b], self.yhat.view(-1), False, out=self.vs[b])       # X_0^T yhat
                 comm.allreduce(self.vs[b])
+                if self.raw:                                                     # uncentred X: X_c^T yhat = X^T yhat - (1^T yhat) mean
+                    be.axpy_scalar(self.vs[b], comm.allreduce(be.total(self.yhat.view(-1))), blk.mean)
                 be.kr_axpy(self.vs[b], blk.A, blk.B, WA, WB, k, c)
                 be.s_downdate(self.S[b], blk.A, blk.B, ya_g, self.wA[b], self.wB[b], self.q, self.vs[b])
             self._s_ready = True

@@ -212,14 +212,17 @@ class tPLS(_EstimatorBase):
         self.X_dim = X.ndim
         self.X_shape = tuple(X.shape)
         self.Y_shape = tuple(Y2.shape)
-        Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=self._copy_X)
+        # a device tensor of the storage type is handed over as it is; the engine clones it before anything writes it (inputs are
+        # never modified, tpls.py:74) -- and not at all when the fit only reads it (algorithm="xcov" without missing values)
+        Xd = to_device_copy(X, _as_torch_dtype(self._dtype, X), dev, copy=False)
         Yd = to_device_copy(Y2, torch.float64, dev)
         def notice(blocks):                                               # during preprocess, before the loop: tpls.py:62-63
             if blocks[0].has_miss:
                 print("X has missing values")
 
         st = eng.fit([Xd], Yd, self.n_components, tol, max_iter, coupled=False, verbose=verbose, algorithm=self._algorithm,
-                     use_graphs=self._graphs, mixed=self._mixed, on_preprocessed=notice)
+                     use_graphs=self._graphs, mixed=self._mixed, on_preprocessed=notice,
+                     owned=[(Xd is not X) or not self._copy_X])
         del Xd
         blk = st.blocks[0]
         self._state = st

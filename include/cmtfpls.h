@@ -137,6 +137,10 @@ int cmtfpls_s_downdate_f64(double* S, int M, int A, int B, const double* ya, con
  *   R2X           |X_{a+1}|^2 = |X_a|^2 - 2 t^T t_b + t^T t  (t_b: the block's own score, = t for one block):
  * two reads of X per component instead of a read and a read + write, and X_0 stays as centred. */
 int cmtfpls_kr_axpy_f64(double* v, int A, int B, const double* WA, const double* WB, int ld, int k, const double* coef, void* stream);
+/* axpy_scalar: y[i] -= a[0] * (x ? x[i] : 1) for n doubles, a on the device.  The two rank-one corrections that let the
+ * cross-covariance loop run on the caller's UNCENTRED X without ever writing or copying it (round 3):
+ *   X_c w = X w - (mean^T w) 1  (scores),   X_c^T yhat = X^T yhat - (1^T yhat) mean  (the down-date of S). */
+int cmtfpls_axpy_scalar_f64(double* y, int64_t n, const double* a, const double* x, void* stream);
 /* Opt-in mixed-precision forms of xcov and mttkrp for f32-stored X: v_mfma_f32_16x16x4_f32 (half the
  * matrix cycles of the f64 form, HBM-bound instead of matrix-pipe-bound).  X is exact; the other
  * operand is rounded once to f32; f32 accumulation only inside chains of 64 rows (xcov) / 256 columns

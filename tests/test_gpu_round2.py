@@ -190,6 +190,9 @@ def test_xcov_without_writing_x_on_gpu(dtype, case, monkeypatch):
         Xs = [a.astype(np.float32).astype(np.float64) for a in Xs]
     fit = O.fit_ctpls(Xs, y, R) if case == "coupled" else O.fit_tpls(Xs[0], y, R)
 
+    # (this test is about writing X or not: the round-3 form that does not even CENTRE it has its own, tests/test_gpu_round3.py)
+    monkeypatch.setattr(NipalsEngine, "xcov_raw", False)
+
     def run(nowrite, keep=None):
         monkeypatch.setattr(NipalsEngine, "xcov_nowrite", nowrite)
         if case == "coupled":

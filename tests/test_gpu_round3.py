@@ -341,3 +341,70 @@ def test_three_coupled_blocks_with_an_empty_row_keep_the_references_nan_semantic
     assert np.all(np.isnan(want[4])) and np.all(np.isnan(got[4]))
     keep = np.arange(12) != 4
     assert _normwise(got[keep], want[keep]) <= 1e-9
+
+
+# ---- algorithm="xcov" on the caller's UNCENTRED tensor: never written, never copied, never centred (round 3) ---------------------
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("case", ["tensor", "coupled", "order4", "matrix"])
+def test_xcov_on_the_uncentred_tensor_equals_the_centred_form(api, monkeypatch, case, dtype):
+    from cmtf_pls_amd.engine import NipalsEngine
+    rng = np.random.default_rng(31)
+    shape = {"tensor": (300, 24, 32), "coupled": (300, 24, 32), "order4": (120, 6, 5, 8), "matrix": (200, 96)}[case]
+    x, y, cp = O.import_synthetic(shape, 5, 4, error=0.1, seed=13)
+    x = x + 7.5                                                   # a mean 20x the spread: the corrections must not cancel badly
+    blocks = [x]
+    if case == "coupled":
+        blocks.append(cp.factors[0] @ rng.normal(size=(64, 4)).T + 0.1 * rng.normal(size=(300, 64)) - 3.0)
+    if dtype == "float32":
+        blocks, y = [_f32(b) for b in blocks], _f32(y)
+    make = (lambda: api.ctPLS(4, dtype=dtype, algorithm="xcov")) if case == "coupled" else (lambda: api.tPLS(4, dtype=dtype, algorithm="xcov"))
+    arg = blocks if case == "coupled" else blocks[0]
+    calls = _count_calls(monkeypatch, ["center", "axpy_scalar", "deflate", "score_deflate", "deflate_contract_yq"])
+    raw = make()
+    raw.fit(arg, y)
+    assert calls["center"] == 1 and calls["axpy_scalar"] > 0                 # (the one centring call is Y's)
+    assert calls["deflate"] == calls["score_deflate"] == calls["deflate_contract_yq"] == 0
+    monkeypatch.setattr(NipalsEngine, "xcov_raw", False)
+    cen = make()
+    cen.fit(arg, y)
+    assert calls["center"] == 1 + 1 + len(blocks)
+    assert raw.n_iter_ == cen.n_iter_
+    tol = 2e-6 if dtype == "float32" else 1e-10                   # f32: the centred copy is rounded once more than the raw tensor
+    Tr = raw.factor_T if case == "coupled" else raw.X_factors[0]
+    Tc = cen.factor_T if case == "coupled" else cen.X_factors[0]
+    assert _normwise(Tr, Tc) <= tol
+    assert _normwise(raw.Y_factors[1], cen.Y_factors[1]) <= tol
+    r2r = raw.R2Xs if case == "coupled" else [raw.R2X]
+    r2c = cen.R2Xs if case == "coupled" else [cen.R2X]
+    for a, b in zip(r2r, r2c):
+        assert_allclose(a, b, rtol=0, atol=tol)
+    assert_allclose(raw.R2Y, cen.R2Y, rtol=0, atol=tol)
+    fit = O.fit_ctpls(blocks, y, 4) if case == "coupled" else O.fit_tpls(blocks[0], y, 4)
+    assert raw.n_iter_ == fit.n_iter
+    assert _normwise(Tr, fit.T) <= (1e-5 if dtype == "float32" else 1e-9)
+    assert_allclose(raw.R2Y, fit.r2y, rtol=0, atol=1e-5 if dtype == "float32" else 1e-10)
+    new = [b[:20] for b in blocks]
+    assert _normwise(raw.transform(new if case == "coupled" else new[0]), O.transform(fit, new if case == "coupled" else new[0])) <= (1e-5 if dtype == "float32" else 1e-9)
+
+
+def test_xcov_fit_of_a_device_tensor_neither_writes_nor_copies_it(api):
+    """tPLS(algorithm="xcov").fit(X_device): X is read 2R + 2 times and that is all -- same bits afterwards, and the fit's peak
+    memory stays far below a second copy of X (inputs are never modified, tpls.py:74, without paying for a clone)."""
+    from cmtf_pls_amd.synthetic import synthetic_shard_device
+    X, Y = synthetic_shard_device((8192, 128, 128), 16, 10, error=0.1, device="cuda:0")          # 537 MB
+    keep = X.clone()
+    m = api.tPLS(5, dtype="float32", algorithm="xcov")
+    m.fit(X, Y, max_iter=30)                                       # warm: workspaces sized
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    m.fit(X, Y, max_iter=30)
+    torch.cuda.synchronize()
+    extra = torch.cuda.max_memory_allocated() - base
+    assert torch.equal(X, keep)
+    assert extra < 0.25 * X.numel() * 4, f"the fit allocated {extra / 1e6:.0f} MB next to a {X.numel() * 4 / 1e6:.0f} MB tensor"
+    d = api.tPLS(5, dtype="float32")                               # the direct loop deflates a private copy; the input stays as it was
+    d.fit(X, Y, max_iter=30)
+    assert torch.equal(X, keep) and d.n_iter_ == m.n_iter_
+    s = np.abs(d.X_factors[0]).max()
+    assert_allclose(m.X_factors[0], d.X_factors[0], rtol=0, atol=1e-5 * s)
