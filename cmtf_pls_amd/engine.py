@@ -218,11 +218,11 @@ class NipalsEngine:
 
     # ------------------------------------------------------------------------------------
     def begin(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool,
-              algorithm: str = "direct", owned: Optional[List[bool]] = None) -> "FitRun":
+              algorithm: str = "direct", owned: Optional[List[bool]] = None, allow_raw: bool = True) -> "FitRun":
         """Preprocess (centre in place) and allocate the per-fit buffers; see FitRun.  owned[b] = False: block b is the
         CALLER's tensor -- it is cloned before anything writes it, and not at all when the fit only reads it."""
         with self.device_ctx():
-            return FitRun(self, Xs, Y, n_components, coupled, algorithm, owned)
+            return FitRun(self, Xs, Y, n_components, coupled, algorithm, owned, allow_raw)
 
     def fit(self, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, tol: float, max_iter: int,
             coupled: bool, verbose: int = 0, algorithm: str = "direct", use_graphs: bool = False,
@@ -234,7 +234,8 @@ class NipalsEngine:
             small = self._fit_small(Xs, Y, n_components, tol, max_iter, coupled, verbose, on_preprocessed)
             if small is not None:
                 return small
-            run = self.begin(Xs, Y, n_components, coupled, algorithm, owned)
+            # (the f32-MFMA S build accumulates in f32 chains: on an uncentred X its error would scale with the means)
+            run = self.begin(Xs, Y, n_components, coupled, algorithm, owned, allow_raw=not mixed)
             if on_preprocessed is not None:                          # the estimators print their missing-value notice
                 on_preprocessed(run.blocks)                          # here, where the reference does (tpls.py:62-63)
             run.tol = tol                                            # also handed to parafac (tpls.py:86)
@@ -461,7 +462,7 @@ class FitRun:
     ``iterate`` directly so that the timed step IS the product's iteration."""
 
     def __init__(self, eng: NipalsEngine, Xs: List[torch.Tensor], Y: torch.Tensor, n_components: int, coupled: bool,
-                 algorithm: str = "direct", owned: Optional[List[bool]] = None):
+                 algorithm: str = "direct", owned: Optional[List[bool]] = None, allow_raw: bool = True):
         be, comm = eng.be, eng.comm
         Xs = list(Xs)
         owned = [True] * len(Xs) if owned is None else list(owned)
@@ -480,7 +481,7 @@ class FitRun:
         self.n_total = int(round(float(n_tot.item())))
         # algorithm="xcov" on blocks without missing values reads X and never writes it (_finish_xcov_nowrite): then it need not be
         # centred either.  The statistics pass decides: raw = every block NaN-free and every kernel of that path present.
-        want_raw = (algorithm == "xcov" and bool(getattr(eng, "xcov_raw", False)) and bool(getattr(eng, "xcov_nowrite", False))
+        want_raw = (allow_raw and algorithm == "xcov" and bool(getattr(eng, "xcov_raw", False)) and bool(getattr(eng, "xcov_nowrite", False))
                     and n_components <= 64
                     and all(hasattr(be, f) for f in ("axpy_scalar", "total", "recon_r2", "s_downdate", "deflate_contract_yq", "kr_axpy")))
         if not want_raw:
