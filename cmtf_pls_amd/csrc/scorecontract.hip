@@ -1,0 +1,161 @@
+// Score and its own contraction in ONE read of X (round 3):
+//   t[i] = sum_c X[i, c] w[c] - shift,        Z[c] = sum_i t[i] X[i, c]        (w[c] = wA[c / B] wB[c % B])
+// i.e. t = X w (multi_mode_dot, tpls.py:97-99) and Z = X x_0 t (np.einsum, tpls.py:83) with the score the same pass just formed.
+// Why it exists: the cross-covariance loop that never writes X (engine.FitRun._finish_xcov_nowrite) needs, per component, the
+// final score t_a and the down-date vector X_{a+1}^T yhat with yhat = T b.  yhat is a combination of the scores, so
+// X_0^T yhat = sum_j b_j (X_0^T t_j): with r_j = X_0^T t_j kept from the pass that produced t_j, the second read of X per component
+// disappears.  t_a = s_a - sum_{j<a} t_j (w_j^T w_a) with s_a = X_0 w_a, hence r_a = X_0^T s_a - sum_{j<a} r_j (w_j^T w_a): the one
+// thing that needs X is p = X_0^T s_a -- this kernel.  (One block only: with coupled blocks the deflation uses the block-averaged
+// score, whose contraction with block b is not something a pass over block b alone can form.)
+//
+// One 1024-thread workgroup per CU walks rows r = blockIdx.x, + gridDim.x, ...; a lane owns the same NV vectors of 16 bytes
+// in every row -- their loading products and NV * V f64 accumulators of Z in registers; the row's dot product is a block sum
+// (one barrier per row), the next row's loads are in flight meanwhile (always issued: a row index clamped to the last row
+// instead of a branch, which would make the compiler wait for every load).  One partial row of Z per workgroup, added in index
+// order by reduce_rows_kernel.  shift (device, nullable): X is uncentred, t = X w - mean^T w.
+// Shapes: B % V == 0, rows of at most 1024 * V * 4 (f32) / 1024 * V * 8 (f64) elements = 16384; no missing values.
+#include "common.hpp"
+
+namespace cmtfpls {
+
+void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, hipStream_t st);
+
+constexpr int kScGrid = 256;
+
+// KC: 1024 * V is a multiple of B, so a lane meets the same mode-2 index in all its vectors -- one set of wB values, not NV.
+template <typename T, int NV, bool KC>
+__global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __restrict__ X, int64_t I, unsigned P, int B,
+                                                                  const double* __restrict__ wA, const double* __restrict__ wB,
+                                                                  const double* __restrict__ shift, double* __restrict__ t,
+                                                                  double* __restrict__ part) {
+  __shared__ double red[2][16];
+  constexpr int V = VecOf<T>::N;
+  using VT = Pack<T, V>;
+  constexpr unsigned stride = 1024u * V;
+  const unsigned c0 = threadIdx.x * V;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double wa[NV], wb[KC ? 1 : NV][V], acc[NV][V];
+  bool ok[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const unsigned c = c0 + n * stride;
+    ok[n] = c < P;
+    const unsigned cg = ok[n] ? c : 0;
+    wa[n] = ok[n] ? wA[cg / (unsigned)B] : 0.0;             // B % V == 0: one j for the whole vector
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      if (!KC || n == 0) wb[KC ? 0 : n][e] = wB[cg % (unsigned)B + e];
+      acc[n][e] = 0.0;
+    }
+  }
+  const double sh = shift ? shift[0] : 0.0;
+  unsigned col[NV];                                           // a vector that does not exist reads column 0 (weight 0): in bounds
+#pragma unroll
+  for (int n = 0; n < NV; ++n) col[n] = ok[n] ? c0 + n * stride : 0u;
+  const int64_t step = gridDim.x;
+  int64_t r = blockIdx.x;
+  VT bufA[NV], bufB[NV];                                     // fixed roles, never copied (a copy would wait for the loads)
+  int parity = 0;
+  auto load = [&](VT (&buf)[NV], int64_t row) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) buf[n] = ld_stream(reinterpret_cast<const VT*>(X + row * (int64_t)P + col[n]));
+  };
+  auto use = [&](VT (&buf)[NV], int64_t row) {
+    double d = 0.0;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      double dn = 0.0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) dn = fma((double)buf[n].e[e], wb[KC ? 0 : n][e], dn);
+      d = fma(wa[n], dn, d);
+    }
+    d = wave_sum(d);
+    if (lane == 0) red[parity][wv] = d;
+    __syncthreads();
+    double ti = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ti += red[parity][q];
+    parity ^= 1;
+    ti -= sh;
+    if (threadIdx.x == 0) t[row] = ti;
+    if constexpr (sizeof(T) == 4) {                          // convert again rather than keep 16 f64 copies alive across the barrier
+#pragma unroll
+      for (int n = 0; n < NV; ++n)
+#pragma unroll
+        for (int e = 0; e < V; ++e) asm volatile("" : "+v"(buf[n].e[e]));
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[n][e] = fma(ti, (double)buf[n].e[e], acc[n][e]);
+  };
+  const int64_t last = I - 1;
+  if (r < I) load(bufA, r);
+  while (r < I) {
+    const int64_t r1 = r + step;
+    load(bufB, r1 < I ? r1 : last);                          // always issued (a clamped row, not a branch around the loads)
+    use(bufA, r);
+    if (r1 >= I) break;
+    const int64_t r2 = r1 + step;
+    load(bufA, r2 < I ? r2 : last);
+    use(bufB, r1);
+    r = r2;
+  }
+  double* __restrict__ prow = part + (int64_t)blockIdx.x * P + c0;
+#pragma unroll
+  for (int n = 0; n < NV; ++n)
+    if (ok[n]) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) prow[n * stride + e] = acc[n][e];
+    }
+}
+
+template <typename T>
+static int run_score_contract(const T* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
+                              double* t, double* Z, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!X || !wA || !wB || !t || !Z || I <= 0 || A <= 0 || B <= 0) { set_error("score_contract: bad argument"); return CMTFPLS_EINVAL; }
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t P = (int64_t)A * B;
+  const int64_t stride = (int64_t)1024 * V;
+  const int nv = (int)((P + stride - 1) / stride);
+  constexpr int kMaxNV = (V == 4) ? 4 : 8;
+  if ((B % V) != 0 || nv > kMaxNV || P < stride / 2 || (reinterpret_cast<uintptr_t>(X) & 15) != 0) {
+    set_error("score_contract: shape outside the row-in-registers form; use score + mode0_contract");
+    return CMTFPLS_EUNSUPPORTED;
+  }
+  const int grid = (int)(I < kScGrid ? I : kScGrid);
+  if (!ws || ws_bytes < (size_t)grid * P * sizeof(double)) { set_error("score_contract: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  double* part = static_cast<double*>(ws);
+  const bool kc = (stride % B) == 0;
+#define SCL(NVV)                                                                                                                  \
+  do {                                                                                                                            \
+    if (kc) hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, t, part); \
+    else hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, false>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, t, part); \
+  } while (0)
+  if (nv <= 1) SCL(1);
+  else if (nv <= 2) SCL(2);
+  else if (nv <= 4) SCL(4);
+  else if constexpr (kMaxNV >= 8) SCL(8);
+#undef SCL
+  launch_reduce_rows(part, grid, P, Z, st);
+  return check_launch("score_contract");
+}
+
+}  // namespace cmtfpls
+
+using namespace cmtfpls;
+
+extern "C" {
+size_t cmtfpls_score_contract_workspace_bytes(int64_t I, int64_t P) {
+  if (I <= 0 || P <= 0) return 0;
+  return (size_t)(I < kScGrid ? I : kScGrid) * (size_t)P * sizeof(double);
+}
+int cmtfpls_score_contract_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
+                               double* t, double* Z, void* ws, size_t ws_bytes, void* stream) {
+  return run_score_contract<float>(X, I, A, B, wA, wB, shift, t, Z, ws, ws_bytes, (hipStream_t)stream);
+}
+int cmtfpls_score_contract_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
+                               double* t, double* Z, void* ws, size_t ws_bytes, void* stream) {
+  return run_score_contract<double>(X, I, A, B, wA, wB, shift, t, Z, ws, ws_bytes, (hipStream_t)stream);
+}
+}

@@ -134,6 +134,9 @@ class NipalsEngine:
     # ... and, when X is never written anyway, do not centre it either (round 3): the fit runs on the caller's UNCENTRED tensor --
     # no centring pass, no private copy -- with two rank-one corrections (FitRun._finish_xcov_nowrite); False keeps the centred copy
     xcov_raw = True
+    # one block: score and the contraction with that score from ONE read of X, the second read per component replaced by a
+    # P x a matrix-vector product (FitRun._finish_xcov_nowrite); False keeps the two reads (tests compare the two)
+    xcov_one_read = True
 
     def __init__(self, backend, comm=None):
         self.be = backend
@@ -598,6 +601,16 @@ class FitRun:
                     self.dot_log = be.zeros(R, 1 + len(self.blocks))
                     self.Gw = be.empty(R * R)
                     self._G_last = None
+                    # one block: the final score and its own contraction r_a = X_0^T t_a come from ONE read of X
+                    # (_finish_xcov_nowrite), so the second read per component is a P x a matrix-vector product instead
+                    self._one_read = (len(self.blocks) == 1 and R > 1 and bool(getattr(eng, "xcov_one_read", False))
+                                      and hasattr(be, "score_contract"))
+                    if self._one_read:
+                        P0 = self.blocks[0].A * self.blocks[0].B
+                        self.ps = be.empty(P0)
+                        self.Rm = be.zeros(P0, R)                                # column j: X_0^T t_j
+                        self.minus_one = be.empty(1)
+                        self.minus_one.fill_(-1.0)
             assert self._nowrite or not self.raw, "an uncentred X needs the form of the loop that never writes it"
 
     def start_component(self, a: int) -> None:
@@ -1062,22 +1075,45 @@ class FitRun:
           R2X        |X_{b,a+1}|^2 = |X_{b,a}|^2 - 2 t^T t_b + t^T t   (t_b: the block's own score; |w_b| = 1)   [result()]
         Two reads of X per component instead of a read and a read + write; the last component needs no second pass
         at all.  X stays as centred.  Same S, same iterations, same scores up to f64 rounding (tests compare this form with
-        the deflating one, `NipalsEngine.xcov_nowrite = False`)."""
+        the deflating one, `NipalsEngine.xcov_nowrite = False`).
+
+        One block (`xcov_one_read`): yhat = T b is a combination of the scores, so X_0^T yhat = sum_j b_j r_j with
+        r_j = X_0^T t_j, and r_a = X_0^T s_a - sum_{j<a} r_j (w_j^T w_a) where s_a = X_0 w_a is the score pass's own result:
+        backend.score_contract forms s_a AND X_0^T s_a in the same read, the r_j are kept (P x R), and the second read of X
+        becomes a P x (a+1) matrix-vector product -- ONE read of X per component.  (Coupled blocks deflate by the
+        block-averaged score, which no pass over a single block can contract with: they keep the two reads.)"""
         be, comm = self.eng.be, self.eng.comm
         self.q = self.qc
         I, R, k = self.I, self.R, a + 1
         nb = len(self.blocks)
         self._store_loadings(a)
+        one_read = False
         for b, blk in enumerate(self.blocks):
-            be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Ts[b])       # X_0 w_a
+            mw = None
             if self.raw:                                                         # uncentred X: X_c w = X w - (mean^T w) 1
                 mw = be.score(blk.mean.view(1, -1), blk.A, blk.B, self.wA[b], self.wB[b], None, be.empty(1))
-                be.axpy_scalar(self.Ts[b], mw)
+            if getattr(self, "_one_read", False) and k < R:
+                # s = X_0 w_a and p = X_0^T s from the same read of X (the block's rows on this rank; p summed over ranks)
+                one_read = be.score_contract(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], mw, self.Ts[b], self.ps) is not None
+                if one_read:
+                    comm.allreduce(self.ps)
+                    if self.raw:                                                 # X_c^T s = X^T s - (1^T s) mean
+                        be.axpy_scalar(self.ps, comm.allreduce(be.total(self.Ts[b])), blk.mean)
+                else:
+                    self._one_read = False                                       # shape outside that kernel: two passes from here on
+            if not one_read:
+                be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Ts[b])   # X_0 w_a
+                if mw is not None:
+                    be.axpy_scalar(self.Ts[b], mw)
             if a > 0:
                 for m, L in enumerate(blk.loadings):                             # Gram of a Khatri-Rao product =
                     be.kr_gram(L, self.Gw, first=(m == 0))                       # Hadamard product of the mode Grams
                 g = self.Gw.view(R, R)[a, :a]                                    # w_j^T w_a, j < a (row a of the symmetric Gram)
                 be.y_deflate(self.Ts[b].view(I, 1), self.T, a, g, self.one)      # t_b -= T[:, :a] g
+                if one_read:                                                     # r_a = X_0^T t_a = p - sum_{j<a} r_j (w_j^T w_a)
+                    be.y_deflate(self.ps.view(-1, 1), self.Rm, a, g, self.one)
+            if one_read:
+                self.Rm[:, a].copy_(self.ps)
         single = self.t.data_ptr() == self.Ts.data_ptr()
         if not single:
             be.scores_mean(self.Ts, self.t)                                      # cmtf.py:120
@@ -1101,10 +1137,14 @@ class FitRun:
             c = be.gram_tn(self._G_last, b_dev).reshape(-1)                      # t_j^T yhat = (T^T T b)_j, j <= a (global)
             for b, blk in enumerate(self.blocks):
                 WA, WB = self.eng._kr_operands(blk, R)                           # columns <= a: the components so far
-                be.mode0_contract(self.X2[b], self.yhat.view(-1), False, out=self.vs[b])       # X_0^T yhat
-                comm.allreduce(self.vs[b])
-                if self.raw:                                                     # uncentred X: X_c^T yhat = X^T yhat - (1^T yhat) mean
-                    be.axpy_scalar(self.vs[b], comm.allreduce(be.total(self.yhat.view(-1))), blk.mean)
+                if one_read:                                                     # X_0^T yhat = sum_j b_j (X_0^T t_j): no read of X
+                    self.vs[b].zero_()
+                    be.y_deflate(self.vs[b].view(-1, 1), self.Rm, k, b_dev, self.minus_one)
+                else:
+                    be.mode0_contract(self.X2[b], self.yhat.view(-1), False, out=self.vs[b])   # X_0^T yhat
+                    comm.allreduce(self.vs[b])
+                    if self.raw:                                                 # uncentred X: X_c^T yhat = X^T yhat - (1^T yhat) mean
+                        be.axpy_scalar(self.vs[b], comm.allreduce(be.total(self.yhat.view(-1))), blk.mean)
                 be.kr_axpy(self.vs[b], blk.A, blk.B, WA, WB, k, c)
                 be.s_downdate(self.S[b], blk.A, blk.B, ya_g, self.wA[b], self.wB[b], self.q, self.vs[b])
             self._s_ready = True

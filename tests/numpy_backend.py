@@ -161,6 +161,15 @@ class NumpyBackend:
         out.copy_(torch.from_numpy(t))
         return out
 
+    def score_contract(self, X2, A, B, wA, wB, shift, t, Z):
+        if X2.shape[1] % 2 == 1:
+            return None        # stands for "row outside the registers of one workgroup": the engine must make the two passes
+        x = _np(X2).astype(np.float64)
+        s = x @ self._w(wA, wB) - (float(shift[0]) if shift is not None else 0.0)
+        t.copy_(torch.from_numpy(s))
+        Z.copy_(torch.from_numpy(x.T @ s))
+        return Z
+
     def deflate(self, X2, A, B, t, wA, wB):
         x = _np(X2)
         x[...] = (x.astype(np.float64) - np.outer(_np(t), self._w(wA, wB))).astype(x.dtype)

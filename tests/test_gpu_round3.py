@@ -388,7 +388,7 @@ def test_xcov_on_the_uncentred_tensor_equals_the_centred_form(api, monkeypatch, 
 
 
 def test_xcov_fit_of_a_device_tensor_neither_writes_nor_copies_it(api):
-    """tPLS(algorithm="xcov").fit(X_device): X is read 2R + 2 times and that is all -- same bits afterwards, and the fit's peak
+    """tPLS(algorithm="xcov").fit(X_device): X is read R + 2 times and that is all -- same bits afterwards, and the fit's peak
     memory stays far below a second copy of X (inputs are never modified, tpls.py:74, without paying for a clone)."""
     from cmtf_pls_amd.synthetic import synthetic_shard_device
     X, Y = synthetic_shard_device((8192, 128, 128), 16, 10, error=0.1, device="cuda:0")          # 537 MB
@@ -408,3 +408,88 @@ def test_xcov_fit_of_a_device_tensor_neither_writes_nor_copies_it(api):
     assert torch.equal(X, keep) and d.n_iter_ == m.n_iter_
     s = np.abs(d.X_factors[0]).max()
     assert_allclose(m.X_factors[0], d.X_factors[0], rtol=0, atol=1e-5 * s)
+
+
+# ---- one read of X per component in the xcov loop: score and its own contraction from the same pass (round 3) -------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("I,A,B,shift", [
+    (300, 128, 128, True),      # the headline row: 4 (f32) / 8 (f64) vectors per lane, one wB set per lane
+    (300, 128, 128, False),
+    (7, 64, 64, True),          # fewer rows than workgroups
+    (513, 100, 60, False),      # ragged row (6000 elements), a lane's vectors meet different mode-2 indices
+    (256, 1, 4096, True),       # a matrix block
+    (257, 3, 5000, False),      # 15000 elements: the last vector of most lanes does not exist
+    (64, 16, 128, True),        # the shortest row the form takes for f32 (half the lanes idle)
+])
+def test_score_contract_kernel_equals_the_two_passes(be, dtype, I, A, B, shift):
+    rng = np.random.default_rng(I + A + B)
+    x = rng.normal(size=(I, A * B)) + 2.0
+    if dtype == torch.float32:
+        x = _f32(x)
+    wA, wB = rng.normal(size=A), rng.normal(size=B)
+    sh = np.array([1.25]) if shift else None
+    X = _dev(x).to(dtype)
+    t, Z = be.empty(I), be.empty(A * B)
+    out = be.score_contract(X, A, B, _dev(wA), _dev(wB), _dev(sh) if shift else None, t, Z)
+    assert out is not None
+    want_t = x @ np.kron(wA, wB) - (1.25 if shift else 0.0)
+    want_Z = x.T @ want_t
+    assert np.abs(t.cpu().numpy() - want_t).max() <= 1e-12 * np.abs(want_t).max()
+    assert np.abs(Z.cpu().numpy() - want_Z).max() <= 1e-12 * np.abs(want_Z).max()
+    # against the two kernels it replaces, same inputs
+    t2 = be.score(X, A, B, _dev(wA), _dev(wB), None, be.empty(I))
+    if shift:
+        t2 -= 1.25
+    Z2 = be.mode0_contract(X, t2, False)
+    assert np.abs((t - t2).cpu().numpy()).max() <= 1e-12 * np.abs(want_t).max()
+    assert np.abs((Z - Z2).cpu().numpy()).max() <= 1e-12 * np.abs(want_Z).max()
+
+
+def test_score_contract_declines_rows_outside_the_registers_of_one_workgroup(be):
+    w = be.zeros(200)
+    for dtype, A, B in ((torch.float32, 200, 128), (torch.float64, 200, 128), (torch.float32, 4, 200), (torch.float32, 64, 66)):
+        X = torch.zeros(8, A * B, dtype=dtype, device="cuda:0")
+        assert be.score_contract(X, A, B, w[:A], w[:B], None, be.empty(8), be.empty(A * B)) is None
+
+
+@pytest.mark.parametrize("raw", [True, False])
+@pytest.mark.parametrize("dtype,shape", [("float32", (400, 128, 128)), ("float64", (300, 64, 128)), ("float32", (500, 4096)),
+                                         ("float32", (300, 8, 16, 32))])
+def test_xcov_fit_with_one_read_per_component_equals_the_two_reads(api, monkeypatch, dtype, shape, raw):
+    """tPLS(algorithm="xcov") on one block reads X once per component (plus the two reads that build S and the norm): the second
+    read is replaced by X_0^T yhat = sum_j b_j r_j with r_j = X_0^T t_j kept from the pass that formed t_j.  Same iterations, same
+    factors as with the two reads (NipalsEngine.xcov_one_read = False) and as the oracle."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    R = 5
+    x, y, _ = O.import_synthetic(shape, 6, 4, error=0.1, seed=17)
+    x = x + 4.0
+    if dtype == "float32":
+        x, y = _f32(x), _f32(y)
+    monkeypatch.setattr(NipalsEngine, "xcov_raw", raw)
+    from cmtf_pls_amd.backend import HipBackend
+    calls = _count_calls(monkeypatch, ["score_contract"])
+    calls["reads"] = 0                                             # passes over the I-row tensor (the inner loop makes the same calls on S)
+    for name in ("mode0_contract", "score"):
+        orig = getattr(HipBackend, name)
+
+        def counted(self, X2, *a, __orig=orig, **k):
+            calls["reads"] += X2.shape[0] == shape[0]
+            return __orig(self, X2, *a, **k)
+        monkeypatch.setattr(HipBackend, name, counted)
+    one = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    one.fit(x, y)
+    assert calls["score_contract"] == R - 1 and calls["reads"] == 1           # the last component's score
+    monkeypatch.setattr(NipalsEngine, "xcov_one_read", False)
+    two = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    two.fit(x, y)
+    assert calls["score_contract"] == R - 1 and calls["reads"] == 1 + R + (R - 1)
+    assert one.n_iter_ == two.n_iter_
+    for f, g in zip(one.X_factors + one.Y_factors, two.X_factors + two.Y_factors):
+        assert _normwise(f, g) <= 1e-10
+    assert_allclose(one.R2X, two.R2X, rtol=0, atol=1e-11)
+    assert_allclose(one.R2Y, two.R2Y, rtol=0, atol=1e-11)
+    assert_allclose(one.coef_, two.coef_, rtol=1e-8, atol=1e-10 * np.abs(two.coef_).max())
+    fit = O.fit_tpls(x, y, R)
+    assert one.n_iter_ == fit.n_iter
+    assert _normwise(one.X_factors[0], fit.T) <= (1e-5 if dtype == "float32" else 1e-9)
+    assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-6 if dtype == "float32" else 1e-9)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How much of a fit's wall time is the GPU busy?  Runs N whole fits (default: xcov, cfg-2 shape) and prints wall time per fit; run it
 under `rocprofv3 --kernel-trace --stats` and divide the summed kernel time by N for the busy time per fit.
-Usage: python tools/fit_busy.py [direct|xcov] [N]"""
+Usage: python tools/fit_busy.py [direct|xcov] [N] [two|one] [f64]      (two: xcov with two reads of X per component, xcov_one_read = False)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,9 +11,12 @@ from cmtf_pls_amd.synthetic import synthetic_shard_device
 
 algo = sys.argv[1] if len(sys.argv) > 1 else "xcov"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+if len(sys.argv) > 3 and sys.argv[3] == "two":
+    NipalsEngine.xcov_one_read = False
 dev = torch.device("cuda:0")
 eng = NipalsEngine(HipBackend(dev), None)
-X, Y = synthetic_shard_device((65536, 128, 128), 16, 10, error=0.1, seed=215, device=dev)
+f64 = len(sys.argv) > 4 and sys.argv[4] == "f64"          # f64 storage: half the rows, the same bytes
+X, Y = synthetic_shard_device((32768 if f64 else 65536, 128, 128), 16, 10, error=0.1, seed=215, device=dev, dtype=torch.float64 if f64 else None)
 walls = []
 for i in range(N + 1):
     Xf, Yf = X.clone(), Y.clone()
