@@ -22,26 +22,54 @@ void launch_reduce_rows(const double* part, int nrows, int64_t P, double* out, h
 
 constexpr int kScGrid = 256;
 
+// Sum over each row of 16 lanes with data-parallel-primitive moves (no LDS, 2 registers): lane ^ 1, lane ^ 2, then the two
+// mirrors (within 8, within 16) -- after the quad steps all lanes of a quad agree, so a mirror adds the other quads.  Every
+// lane of the row ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const uint64_t b = __double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_move<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+  v += dpp_move<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+  v += dpp_move<0x141>(v);     // row_half_mirror
+  v += dpp_move<0x140>(v);     // row_mirror
+  return v;
+}
+
 // KC: 1024 * V is a multiple of B, so a lane meets the same mode-2 index in all its vectors -- one set of wB values, not NV.
-template <typename T, int NV, bool KC>
+// WL (the 8-vector rows of f64 storage, where 2 x 32 registers of rows in flight + 32 of accumulators leave no room): KC, every
+// vector exists (P = NV * 1024 * V) and A <= kScLdsA -- the mode-1 loadings are read from LDS per row instead of held, and the
+// column offsets are compile-time multiples of the stride.
+constexpr int kScLdsA = 2048;
+template <typename T, int NV, bool KC, bool WL = false>
 __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __restrict__ X, int64_t I, unsigned P, int B,
                                                                   const double* __restrict__ wA, const double* __restrict__ wB,
                                                                   const double* __restrict__ shift, double* __restrict__ t,
                                                                   double* __restrict__ part) {
   __shared__ double red[2][16];
+  __shared__ double wls[WL ? kScLdsA : 1];
   constexpr int V = VecOf<T>::N;
   using VT = Pack<T, V>;
   constexpr unsigned stride = 1024u * V;
   const unsigned c0 = threadIdx.x * V;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double wa[NV], wb[KC ? 1 : NV][V], acc[NV][V];
+  double wa[WL ? 1 : NV], wb[KC ? 1 : NV][V], acc[NV][V];
   bool ok[NV];
+  const unsigned j0 = c0 / (unsigned)B, jstep = stride / (unsigned)B;     // WL: vector n of this lane is in mode-1 slice j0 + n * jstep
+  if constexpr (WL) {
+    for (unsigned j = threadIdx.x; j < NV * jstep; j += 1024) wls[(j % jstep) * NV + j / jstep] = wA[j];   // [slice within the stride][vector]
+    __syncthreads();
+  }
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
     const unsigned c = c0 + n * stride;
-    ok[n] = c < P;
+    ok[n] = WL || c < P;
     const unsigned cg = ok[n] ? c : 0;
-    wa[n] = ok[n] ? wA[cg / (unsigned)B] : 0.0;             // B % V == 0: one j for the whole vector
+    if constexpr (!WL) wa[n] = ok[n] ? wA[cg / (unsigned)B] : 0.0;      // B % V == 0: one j for the whole vector
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       if (!KC || n == 0) wb[KC ? 0 : n][e] = wB[cg % (unsigned)B + e];
@@ -49,16 +77,26 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
     }
   }
   const double sh = shift ? shift[0] : 0.0;
-  unsigned col[NV];                                           // a vector that does not exist reads column 0 (weight 0): in bounds
+  unsigned col[WL ? 1 : NV];                                  // a vector that does not exist reads column 0 (weight 0): in bounds
+  if constexpr (!WL) {
 #pragma unroll
-  for (int n = 0; n < NV; ++n) col[n] = ok[n] ? c0 + n * stride : 0u;
+    for (int n = 0; n < NV; ++n) col[n] = ok[n] ? c0 + n * stride : 0u;
+  }
   const int64_t step = gridDim.x;
   int64_t r = blockIdx.x;
   VT bufA[NV], bufB[NV];                                     // fixed roles, never copied (a copy would wait for the loads)
   int parity = 0;
   auto load = [&](VT (&buf)[NV], int64_t row) {
 #pragma unroll
-    for (int n = 0; n < NV; ++n) buf[n] = ld_stream(reinterpret_cast<const VT*>(X + row * (int64_t)P + col[n]));
+    for (int n = 0; n < NV; ++n) {
+      if constexpr (WL) {                                    // uniform base per vector + ONE lane offset: no per-vector address registers
+        const uint64_t o = (uint64_t)(row * (int64_t)P + (int64_t)n * stride);      // made visibly uniform: scalar base, one lane offset
+        const uint64_t ou = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)o);
+        buf[n] = ld_stream(reinterpret_cast<const VT*>(X + ou + c0));
+      } else {
+        buf[n] = ld_stream(reinterpret_cast<const VT*>(X + row * (int64_t)P + col[n]));
+      }
+    }
   };
   auto use = [&](VT (&buf)[NV], int64_t row) {
     double d = 0.0;
@@ -67,16 +105,13 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
       double dn = 0.0;
 #pragma unroll
       for (int e = 0; e < V; ++e) dn = fma((double)buf[n].e[e], wb[KC ? 0 : n][e], dn);
-      d = fma(wa[n], dn, d);
+      d = fma(WL ? wls[j0 * NV + n] : wa[WL ? 0 : n], dn, d);       // (WL: the lane's NV loadings are contiguous in LDS)
     }
     d = wave_sum(d);
     if (lane == 0) red[parity][wv] = d;
     __syncthreads();
-    double ti = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) ti += red[parity][q];
+    double ti = row16_sum(red[parity][lane & 15]) - sh;          // the 16 wavefronts' partial sums, one per lane of a row
     parity ^= 1;
-    ti -= sh;
     if (threadIdx.x == 0) t[row] = ti;
     if constexpr (sizeof(T) == 4) {                          // convert again rather than keep 16 f64 copies alive across the barrier
 #pragma unroll
@@ -135,7 +170,11 @@ static int run_score_contract(const T* X, int64_t I, int A, int B, const double*
   if (nv <= 1) SCL(1);
   else if (nv <= 2) SCL(2);
   else if (nv <= 4) SCL(4);
-  else if constexpr (kMaxNV >= 8) SCL(8);
+  else if constexpr (kMaxNV >= 8) {
+    if (kc && P == 8 * stride && A <= kScLdsA)
+      hipLaunchKernelGGL((score_contract_rows_kernel<T, 8, true, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, t, part);
+    else SCL(8);
+  }
 #undef SCL
   launch_reduce_rows(part, grid, P, Z, st);
   return check_launch("score_contract");
