@@ -216,16 +216,18 @@ class HipBackend:
         _lib.check(self._fn("score", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), self._stream()), "score")
         return out
 
-    def score_contract(self, X2, A, B, wA, wB, shift, t, Z) -> Optional[torch.Tensor]:
-        """t = X w - shift and Z = X^T t in one read of X (cmtfpls_score_contract_*); None when the row does not fit the registers
-        of one workgroup (the caller then makes the two passes)."""
+    def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha: float = 1.0) -> Optional[torch.Tensor]:
+        """t = X w - shift - sub_own and Z = X^T (alpha (t + add_other)) in one read of X (cmtfpls_score_contract_*); None when the
+        row does not fit the registers of one workgroup (the caller then makes the two passes)."""
         I, P = X2.shape
         if not X2.is_contiguous() or P != A * B:
             return None
+        for v in (sub_own, add_other):
+            assert v is None or (v.is_contiguous() and v.numel() == I and v.dtype == torch.float64)
         nbytes = self.lib.cmtfpls_score_contract_workspace_bytes(I, P)
         ws = self._workspace("score_contract", max(nbytes, 256))
-        rc = self._fn("score_contract", X2)(_ptr(X2), I, A, B, _ptr(wA), _ptr(wB), _ptr(shift), _ptr(t), _ptr(Z), _ptr(ws), ws.numel(),
-                                            self._stream())
+        rc = self._fn("score_contract", X2)(_ptr(X2), I, A, B, _ptr(wA), _ptr(wB), _ptr(shift), _ptr(sub_own), _ptr(add_other), float(alpha),
+                                            _ptr(t), _ptr(Z), _ptr(ws), ws.numel(), self._stream())
         if rc == 4:
             return None
         _lib.check(rc, "score_contract")

@@ -1,6 +1,9 @@
-// Score and its own contraction in ONE read of X (round 3):
-//   t[i] = sum_c X[i, c] w[c] - shift,        Z[c] = sum_i t[i] X[i, c]        (w[c] = wA[c / B] wB[c % B])
-// i.e. t = X w (multi_mode_dot, tpls.py:97-99) and Z = X x_0 t (np.einsum, tpls.py:83) with the score the same pass just formed.
+// Score and the contraction with that score in ONE read of X (round 3):
+//   t[i] = sum_c X[i, c] w[c] - shift - sub_own[i],    c[i] = alpha (t[i] + add_other[i]),    Z[col] = sum_i c[i] X[i, col]
+// (w[c] = wA[c / B] wB[c % B]; shift, sub_own, add_other nullable = 0), i.e. t = X w (multi_mode_dot, tpls.py:97-99) and
+// Z = X x_0 c (np.einsum, tpls.py:83) with a score the same pass just formed.  sub_own = T[:, :a] (w_j^T w_a)_j turns X_0 w into the
+// score of the implicitly deflated X_a; add_other = the other coupled blocks' scores and alpha = 1 / blocks make c the
+// block-AVERAGED score (cmtf.py:120) the deflation uses -- so Z = X_0^T t_a for the block that is read last.
 // Why it exists: the cross-covariance loop that never writes X (engine.FitRun._finish_xcov_nowrite) needs, per component, the
 // final score t_a and the down-date vector X_{a+1}^T yhat with yhat = T b.  yhat is a combination of the scores, so
 // X_0^T yhat = sum_j b_j (X_0^T t_j): with r_j = X_0^T t_j kept from the pass that produced t_j, the second read of X per component
@@ -48,8 +51,9 @@ constexpr int kScLdsA = 2048;
 template <typename T, int NV, bool KC, bool WL = false>
 __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __restrict__ X, int64_t I, unsigned P, int B,
                                                                   const double* __restrict__ wA, const double* __restrict__ wB,
-                                                                  const double* __restrict__ shift, double* __restrict__ t,
-                                                                  double* __restrict__ part) {
+                                                                  const double* __restrict__ shift, const double* __restrict__ sub_own,
+                                                                  const double* __restrict__ add_other, double alpha,
+                                                                  double* __restrict__ t, double* __restrict__ part) {
   __shared__ double red[2][16];
   __shared__ double wls[WL ? kScLdsA : 1];
   constexpr int V = VecOf<T>::N;
@@ -112,7 +116,10 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
     __syncthreads();
     double ti = row16_sum(red[parity][lane & 15]) - sh;          // the 16 wavefronts' partial sums, one per lane of a row
     parity ^= 1;
+    if (sub_own) ti -= sub_own[row];
     if (threadIdx.x == 0) t[row] = ti;
+    if (add_other) ti += add_other[row];
+    ti *= alpha;
     if constexpr (sizeof(T) == 4) {                          // convert again rather than keep 16 f64 copies alive across the barrier
 #pragma unroll
       for (int n = 0; n < NV; ++n)
@@ -147,7 +154,8 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
 
 template <typename T>
 static int run_score_contract(const T* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                              double* t, double* Z, void* ws, size_t ws_bytes, hipStream_t st) {
+                              const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
+                              size_t ws_bytes, hipStream_t st) {
   if (!X || !wA || !wB || !t || !Z || I <= 0 || A <= 0 || B <= 0) { set_error("score_contract: bad argument"); return CMTFPLS_EINVAL; }
   constexpr int V = 16 / (int)sizeof(T);
   const int64_t P = (int64_t)A * B;
@@ -164,15 +172,15 @@ static int run_score_contract(const T* X, int64_t I, int A, int B, const double*
   const bool kc = (stride % B) == 0;
 #define SCL(NVV)                                                                                                                  \
   do {                                                                                                                            \
-    if (kc) hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, t, part); \
-    else hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, false>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, t, part); \
+    if (kc) hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part); \
+    else hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, false>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part); \
   } while (0)
   if (nv <= 1) SCL(1);
   else if (nv <= 2) SCL(2);
   else if (nv <= 4) SCL(4);
   else if constexpr (kMaxNV >= 8) {
     if (kc && P == 8 * stride && A <= kScLdsA)
-      hipLaunchKernelGGL((score_contract_rows_kernel<T, 8, true, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, t, part);
+      hipLaunchKernelGGL((score_contract_rows_kernel<T, 8, true, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part);
     else SCL(8);
   }
 #undef SCL
@@ -190,11 +198,13 @@ size_t cmtfpls_score_contract_workspace_bytes(int64_t I, int64_t P) {
   return (size_t)(I < kScGrid ? I : kScGrid) * (size_t)P * sizeof(double);
 }
 int cmtfpls_score_contract_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               double* t, double* Z, void* ws, size_t ws_bytes, void* stream) {
-  return run_score_contract<float>(X, I, A, B, wA, wB, shift, t, Z, ws, ws_bytes, (hipStream_t)stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
+                               size_t ws_bytes, void* stream) {
+  return run_score_contract<float>(X, I, A, B, wA, wB, shift, sub_own, add_other, alpha, t, Z, ws, ws_bytes, (hipStream_t)stream);
 }
 int cmtfpls_score_contract_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               double* t, double* Z, void* ws, size_t ws_bytes, void* stream) {
-  return run_score_contract<double>(X, I, A, B, wA, wB, shift, t, Z, ws, ws_bytes, (hipStream_t)stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
+                               size_t ws_bytes, void* stream) {
+  return run_score_contract<double>(X, I, A, B, wA, wB, shift, sub_own, add_other, alpha, t, Z, ws, ws_bytes, (hipStream_t)stream);
 }
 }

@@ -601,14 +601,15 @@ class FitRun:
                     self.dot_log = be.zeros(R, 1 + len(self.blocks))
                     self.Gw = be.empty(R * R)
                     self._G_last = None
-                    # one block: the final score and its own contraction r_a = X_0^T t_a come from ONE read of X
-                    # (_finish_xcov_nowrite), so the second read per component is a P x a matrix-vector product instead
-                    self._one_read = (len(self.blocks) == 1 and R > 1 and bool(getattr(eng, "xcov_one_read", False))
-                                      and hasattr(be, "score_contract"))
+                    # the final score and r_a = X_0^T t_a of the LARGEST block come from ONE read of it (_finish_xcov_nowrite),
+                    # so its second read per component is a P x a matrix-vector product instead
+                    self._one_read = R > 1 and bool(getattr(eng, "xcov_one_read", False)) and hasattr(be, "score_contract")
                     if self._one_read:
-                        P0 = self.blocks[0].A * self.blocks[0].B
+                        self._fused_b = max(range(len(self.blocks)), key=lambda b: self.blocks[b].A * self.blocks[b].B)
+                        P0 = self.blocks[self._fused_b].A * self.blocks[self._fused_b].B
                         self.ps = be.empty(P0)
                         self.Rm = be.zeros(P0, R)                                # column j: X_0^T t_j
+                        self.corr = be.empty(I)
                         self.minus_one = be.empty(1)
                         self.minus_one.fill_(-1.0)
             assert self._nowrite or not self.raw, "an uncentred X needs the form of the loop that never writes it"
@@ -1077,46 +1078,59 @@ class FitRun:
         at all.  X stays as centred.  Same S, same iterations, same scores up to f64 rounding (tests compare this form with
         the deflating one, `NipalsEngine.xcov_nowrite = False`).
 
-        One block (`xcov_one_read`): yhat = T b is a combination of the scores, so X_0^T yhat = sum_j b_j r_j with
-        r_j = X_0^T t_j, and r_a = X_0^T s_a - sum_{j<a} r_j (w_j^T w_a) where s_a = X_0 w_a is the score pass's own result:
-        backend.score_contract forms s_a AND X_0^T s_a in the same read, the r_j are kept (P x R), and the second read of X
-        becomes a P x (a+1) matrix-vector product -- ONE read of X per component.  (Coupled blocks deflate by the
-        block-averaged score, which no pass over a single block can contract with: they keep the two reads.)"""
+        `xcov_one_read`: yhat = T b is a combination of the scores, so X_0^T yhat = sum_j b_j r_j with r_j = X_0^T t_j.  The
+        score pass over a block can form r_a itself, in the same read, once everything else t_a is made of is known:
+        t_a = mean_b t_b (cmtf.py:120), t_b = X_{b,0} w_{b,a} - T[:, :a] g_b -- the correction T g_b is known before the pass
+        and so are the other blocks' scores if this block is read LAST.  backend.score_contract forms t_b and X_0^T t_a per
+        row (dot product, then the row times the averaged score); the r_j are kept (P x R) and the block's second read per
+        component becomes a P x (a+1) matrix-vector product.  Applied to the largest block (the only one of a tPLS fit: ONE
+        read of X per component); the other blocks of a coupled fit keep their two reads."""
         be, comm = self.eng.be, self.eng.comm
         self.q = self.qc
         I, R, k = self.I, self.R, a + 1
         nb = len(self.blocks)
         self._store_loadings(a)
+        fused_b = self._fused_b if (getattr(self, "_one_read", False) and k < R) else -1
         one_read = False
-        for b, blk in enumerate(self.blocks):
+        for b in [x for x in range(nb) if x != fused_b] + ([fused_b] if fused_b >= 0 else []):      # the fused block is read last
+            blk = self.blocks[b]
             mw = None
             if self.raw:                                                         # uncentred X: X_c w = X w - (mean^T w) 1
                 mw = be.score(blk.mean.view(1, -1), blk.A, blk.B, self.wA[b], self.wB[b], None, be.empty(1))
-            if getattr(self, "_one_read", False) and k < R:
-                # s = X_0 w_a and p = X_0^T s from the same read of X (the block's rows on this rank; p summed over ranks)
-                one_read = be.score_contract(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], mw, self.Ts[b], self.ps) is not None
-                if one_read:
-                    comm.allreduce(self.ps)
-                    if self.raw:                                                 # X_c^T s = X^T s - (1^T s) mean
-                        be.axpy_scalar(self.ps, comm.allreduce(be.total(self.Ts[b])), blk.mean)
-                else:
-                    self._one_read = False                                       # shape outside that kernel: two passes from here on
-            if not one_read:
-                be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Ts[b])   # X_0 w_a
-                if mw is not None:
-                    be.axpy_scalar(self.Ts[b], mw)
+            g = None
             if a > 0:
                 for m, L in enumerate(blk.loadings):                             # Gram of a Khatri-Rao product =
                     be.kr_gram(L, self.Gw, first=(m == 0))                       # Hadamard product of the mode Grams
                 g = self.Gw.view(R, R)[a, :a]                                    # w_j^T w_a, j < a (row a of the symmetric Gram)
+            if b == fused_b:
+                # t_b = X_0 w_a - T[:, :a] g and r_a = X_0^T t_a (t_a: the average over the blocks, cmtf.py:120) from the same read
+                # of X (this rank's rows; r_a summed over ranks below)
+                corr = others = None
+                if a > 0:
+                    be.rowdot(self.T[:, :a], g, self.corr, None)                 # T[:, :a] g
+                    corr = self.corr
+                if nb == 2:
+                    others = self.Ts[1 - b]                                      # (the other blocks' scores are final by now)
+                elif nb > 2:
+                    others = self.Ts[[x for x in range(nb) if x != b]].sum(dim=0)
+                one_read = be.score_contract(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], mw, self.Ts[b], self.ps,
+                                             sub_own=corr, add_other=others, alpha=1.0 / nb) is not None
+                if one_read:
+                    continue
+                self._one_read = False                                           # shape outside that kernel: two passes from here on
+            be.score(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Ts[b])       # X_0 w_a
+            if mw is not None:
+                be.axpy_scalar(self.Ts[b], mw)
+            if a > 0:
                 be.y_deflate(self.Ts[b].view(I, 1), self.T, a, g, self.one)      # t_b -= T[:, :a] g
-                if one_read:                                                     # r_a = X_0^T t_a = p - sum_{j<a} r_j (w_j^T w_a)
-                    be.y_deflate(self.ps.view(-1, 1), self.Rm, a, g, self.one)
-            if one_read:
-                self.Rm[:, a].copy_(self.ps)
         single = self.t.data_ptr() == self.Ts.data_ptr()
         if not single:
             be.scores_mean(self.Ts, self.t)                                      # cmtf.py:120
+        if one_read:
+            comm.allreduce(self.ps)
+            if self.raw:                                                         # X_c^T t = X^T t - (1^T t) mean
+                be.axpy_scalar(self.ps, comm.allreduce(be.total(self.t)), self.blocks[fused_b].mean)
+            self.Rm[:, a].copy_(self.ps)
         be.rowdot(self.Y, self.q, self.u, None)                                  # u = Y q (tpls.py:102)
         be.gram_tn(self.t, self.t, out=self.dot_log[a, 0:1])
         for b in range(nb):
@@ -1137,7 +1151,7 @@ class FitRun:
             c = be.gram_tn(self._G_last, b_dev).reshape(-1)                      # t_j^T yhat = (T^T T b)_j, j <= a (global)
             for b, blk in enumerate(self.blocks):
                 WA, WB = self.eng._kr_operands(blk, R)                           # columns <= a: the components so far
-                if one_read:                                                     # X_0^T yhat = sum_j b_j (X_0^T t_j): no read of X
+                if one_read and b == fused_b:                                    # X_0^T yhat = sum_j b_j (X_0^T t_j): no read of X
                     self.vs[b].zero_()
                     be.y_deflate(self.vs[b].view(-1, 1), self.Rm, k, b_dev, self.minus_one)
                 else:

@@ -141,19 +141,24 @@ int cmtfpls_kr_axpy_f64(double* v, int A, int B, const double* WA, const double*
  * cross-covariance loop run on the caller's UNCENTRED X without ever writing or copying it (round 3):
  *   X_c w = X w - (mean^T w) 1  (scores),   X_c^T yhat = X^T yhat - (1^T yhat) mean  (the down-date of S). */
 int cmtfpls_axpy_scalar_f64(double* y, int64_t n, const double* a, const double* x, void* stream);
-/* score_contract (round 3): t = X w - shift[0] (shift nullable) AND Z = X^T t in ONE read of X  (w[c] = wA[c/B] wB[c%B];
- * multi_mode_dot, tpls.py:97-99, followed by np.einsum("i...,i->...", X, t), tpls.py:83, with the score just formed).
- * Removes the second read of X per component from the never-writing cross-covariance loop above: with r_j = X_0^T t_j kept for
- * every component, X_0^T yhat = sum_j b_j r_j (yhat = T b), and r_a = X_0^T s_a - sum_{j<a} r_j (w_j^T w_a) where s_a = X_0 w_a
- * and X_0^T s_a is this entry's Z.  One block only (coupled blocks deflate by the block-averaged score).
+/* score_contract (round 3): ONE read of X gives a score and the contraction with it,
+ *   t[i] = sum_c X[i,c] w[c] - shift[0] - sub_own[i],   c[i] = alpha (t[i] + add_other[i]),   Z = X^T c
+ * (w[c] = wA[c/B] wB[c%B]; shift, sub_own, add_other nullable = 0): multi_mode_dot, tpls.py:97-99, followed by
+ * np.einsum("i...,i->...", X, c), tpls.py:83, with a score the pass just formed.  It removes the second read of X per component
+ * from the never-writing cross-covariance loop above: yhat = T b is a combination of the scores, so X_0^T yhat = sum_j b_j r_j with
+ * r_j = X_0^T t_j kept from the pass that formed t_j.  sub_own = T[:, :a] (w_j^T w_a)_j makes t the score of the implicitly
+ * deflated X_a; for coupled blocks (cmtf.py:120) add_other = the sum of the other blocks' scores and alpha = 1 / blocks make c the
+ * block-averaged score the deflation uses, for the block that is read last.
  * A row lives in the registers of one 1024-thread workgroup: B % (16 / sizeof) == 0, 512 * (16 / sizeof) <= A * B <= 16384, no
  * missing values; CMTFPLS_EUNSUPPORTED otherwise (use cmtfpls_score_* + cmtfpls_mode0_contract_*).
  * ws: cmtfpls_score_contract_workspace_bytes(I, A * B). */
 size_t cmtfpls_score_contract_workspace_bytes(int64_t I, int64_t P);
 int cmtfpls_score_contract_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               double* t, double* Z, void* ws, size_t ws_bytes, void* stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
+                               size_t ws_bytes, void* stream);
 int cmtfpls_score_contract_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               double* t, double* Z, void* ws, size_t ws_bytes, void* stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
+                               size_t ws_bytes, void* stream);
 /* Opt-in mixed-precision forms of xcov and mttkrp for f32-stored X: v_mfma_f32_16x16x4_f32 (half the
  * matrix cycles of the f64 form, HBM-bound instead of matrix-pipe-bound).  X is exact; the other
  * operand is rounded once to f32; f32 accumulation only inside chains of 64 rows (xcov) / 256 columns

@@ -161,13 +161,16 @@ class NumpyBackend:
         out.copy_(torch.from_numpy(t))
         return out
 
-    def score_contract(self, X2, A, B, wA, wB, shift, t, Z):
+    def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha=1.0):
         if X2.shape[1] % 2 == 1:
             return None        # stands for "row outside the registers of one workgroup": the engine must make the two passes
         x = _np(X2).astype(np.float64)
         s = x @ self._w(wA, wB) - (float(shift[0]) if shift is not None else 0.0)
+        if sub_own is not None:
+            s = s - _np(sub_own)
         t.copy_(torch.from_numpy(s))
-        Z.copy_(torch.from_numpy(x.T @ s))
+        c = alpha * (s + (_np(add_other) if add_other is not None else 0.0))
+        Z.copy_(torch.from_numpy(x.T @ c))
         return Z
 
     def deflate(self, X2, A, B, t, wA, wB):

@@ -256,49 +256,64 @@ def test_xcov_without_writing_x_equals_the_deflating_form(case, monkeypatch):
     np.testing.assert_allclose(Xd.numpy(), Xs[0] - Xs[0].mean(axis=0), rtol=0, atol=1e-13)
 
 
-@pytest.mark.parametrize("case", ["tpls3", "tpls4", "matrix", "declined", "more_components_than_rank"])
+@pytest.mark.parametrize("case", ["tpls3", "tpls4", "matrix", "declined", "more_components_than_rank", "coupled2", "coupled3"])
 def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
-    """One block: the final score and r_a = X_0^T t_a from ONE read of X (score_contract), the down-date vector X_0^T yhat =
-    sum_j b_j r_j from the kept r_j instead of a second read (FitRun._finish_xcov_nowrite).  Same fit as with the two reads
+    """The final score of the largest block and r_a = X_0^T t_a from ONE read of it (score_contract), its down-date vector
+    X_0^T yhat = sum_j b_j r_j from the kept r_j instead of a second read (FitRun._finish_xcov_nowrite); with coupled blocks the
+    kernel is handed the other blocks' scores and contracts with the block average.  Same fit as with the two reads
     (NipalsEngine.xcov_one_read = False); "declined": the backend refuses the shape and the engine makes the two passes."""
     from cmtf_pls_amd.engine import NipalsEngine
     rng = np.random.default_rng(78)
     R = 4
     shape = {"tpls3": (30, 7, 6), "tpls4": (30, 6, 5, 4), "matrix": (30, 24), "declined": (30, 7, 5),
-             "more_components_than_rank": (30, 7, 6)}[case]
+             "more_components_than_rank": (30, 7, 6), "coupled2": (30, 7, 6), "coupled3": (30, 7, 6)}[case]
     if case == "more_components_than_rank":
         x, _, _ = O.import_synthetic(shape, 3, 2, error=0.0, seed=3)
     else:
         x = rng.random(shape) + 3.0
+    blocks = [x]
+    if case.startswith("coupled"):
+        blocks = [rng.random((30, 9)) - 1.0, x] + ([rng.random((30, 3, 4))] if case == "coupled3" else [])   # the largest is not the first
     Y = rng.random((30, 3))
-    calls = {"n": 0, "took": 0}
+    calls = {"n": 0, "took": 0, "P": set()}
     orig = NumpyBackend.score_contract
 
-    def counted(self, *a):
-        out = orig(self, *a)
+    def counted(self, X2, *a, **kw):
+        out = orig(self, X2, *a, **kw)
         calls["n"] += 1
         calls["took"] += out is not None
+        calls["P"].add(X2.shape[1])
         return out
     monkeypatch.setattr(NumpyBackend, "score_contract", counted)
 
     def fit(one_read):
         monkeypatch.setattr(NipalsEngine, "xcov_one_read", one_read)
-        m = tPLS(R, backend=NumpyBackend(), algorithm="xcov")
-        m.fit(x, Y)
+        m = (ctPLS if len(blocks) > 1 else tPLS)(R, backend=NumpyBackend(), algorithm="xcov")
+        m.fit(blocks if len(blocks) > 1 else x, Y)
         return m
 
     two = fit(False)
     assert calls["n"] == 0
     one = fit(True)
     if case == "declined":
-        assert calls == {"n": 1, "took": 0}                      # asked once, refused, not asked again
+        assert (calls["n"], calls["took"]) == (1, 0)             # asked once, refused, not asked again
     else:
-        assert calls == {"n": R - 1, "took": R - 1}              # the last component needs no down-date
+        assert (calls["n"], calls["took"]) == (R - 1, R - 1)     # the last component needs no down-date
+        assert calls["P"] == {int(np.prod(shape[1:]))}           # ... and only the largest block is read this way
     ncmp = 2 if case == "more_components_than_rank" else R
     assert one.n_iter_[:ncmp] == two.n_iter_[:ncmp]
-    for f, g in zip(one.X_factors + one.Y_factors, two.X_factors + two.Y_factors):
+    if len(blocks) > 1:
+        f1 = [one.factor_T] + [f for fs in one.Xs_factors for f in fs[1:]] + list(one.Y_factors)
+        f2 = [two.factor_T] + [f for fs in two.Xs_factors for f in fs[1:]] + list(two.Y_factors)
+        r1, r2 = np.concatenate(one.R2Xs), np.concatenate(two.R2Xs)
+    else:
+        f1, f2, r1, r2 = one.X_factors + one.Y_factors, two.X_factors + two.Y_factors, one.R2X, two.R2X
+    for f, g in zip(f1, f2):
         np.testing.assert_allclose(f[:, :ncmp], g[:, :ncmp], rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(one.R2X[:ncmp], two.R2X[:ncmp], rtol=0, atol=1e-10)
+    if len(blocks) == 1:
+        np.testing.assert_allclose(r1[:ncmp], r2[:ncmp], rtol=0, atol=1e-10)
+    else:
+        np.testing.assert_allclose(r1, r2, rtol=0, atol=1e-10)
     np.testing.assert_allclose(one.R2Y[:ncmp], two.R2Y[:ncmp], rtol=0, atol=1e-10)
     np.testing.assert_allclose(one.coef_[:ncmp, :ncmp], two.coef_[:ncmp, :ncmp], rtol=1e-8, atol=1e-10)
 

@@ -443,6 +443,13 @@ def test_score_contract_kernel_equals_the_two_passes(be, dtype, I, A, B, shift):
     Z2 = be.mode0_contract(X, t2, False)
     assert np.abs((t - t2).cpu().numpy()).max() <= 1e-12 * np.abs(want_t).max()
     assert np.abs((Z - Z2).cpu().numpy()).max() <= 1e-12 * np.abs(want_Z).max()
+    # the coupled form: own correction, the other blocks' scores, the block average
+    sub, oth = rng.normal(size=I) * 10, rng.normal(size=I) * 10
+    out = be.score_contract(X, A, B, _dev(wA), _dev(wB), _dev(sh) if shift else None, t, Z, sub_own=_dev(sub), add_other=_dev(oth), alpha=0.5)
+    assert out is not None
+    want_c = 0.5 * (want_t - sub + oth)
+    assert np.abs(t.cpu().numpy() - (want_t - sub)).max() <= 1e-12 * np.abs(want_t).max()
+    assert np.abs(Z.cpu().numpy() - x.T @ want_c).max() <= 1e-12 * np.abs(x.T @ want_c).max()
 
 
 def test_score_contract_declines_rows_outside_the_registers_of_one_workgroup(be):
@@ -493,3 +500,47 @@ def test_xcov_fit_with_one_read_per_component_equals_the_two_reads(api, monkeypa
     assert one.n_iter_ == fit.n_iter
     assert _normwise(one.X_factors[0], fit.T) <= (1e-5 if dtype == "float32" else 1e-9)
     assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-6 if dtype == "float32" else 1e-9)
+
+
+@pytest.mark.parametrize("raw", [True, False])
+@pytest.mark.parametrize("extra", [1, 2])
+def test_xcov_coupled_fit_reads_the_largest_block_once_per_component(api, monkeypatch, raw, extra):
+    """ctPLS(algorithm="xcov"): the deflation uses the block-AVERAGED score, so the pass over the largest block is handed the other
+    blocks' scores (read first) and contracts with the average; the small blocks keep their two reads.  Same fit as with two
+    reads everywhere, and as the oracle."""
+    from cmtf_pls_amd.backend import HipBackend
+    from cmtf_pls_amd.engine import NipalsEngine
+    R, I = 5, 300
+    rng = np.random.default_rng(5)
+    x, y, cp = O.import_synthetic((I, 64, 64), 6, 4, error=0.1, seed=19)
+    blocks = [cp.factors[0] @ rng.normal(size=(96, 4)).T + 0.1 * rng.normal(size=(I, 96)) - 2.0, _f32(x + 4.0)]     # the largest is second
+    if extra == 2:
+        blocks.append(np.einsum("ir,jr,kr->ijk", cp.factors[0], rng.normal(size=(6, 4)), rng.normal(size=(8, 4))) + 0.1 * rng.normal(size=(I, 6, 8)))
+    blocks = [_f32(b) for b in blocks]
+    y = _f32(y)
+    monkeypatch.setattr(NipalsEngine, "xcov_raw", raw)
+    seen = []
+    orig = HipBackend.score_contract
+
+    def counted(self, X2, *a, **k):
+        out = orig(self, X2, *a, **k)
+        seen.append((X2.shape[1], out is not None, k.get("alpha")))
+        return out
+    monkeypatch.setattr(HipBackend, "score_contract", counted)
+    one = api.ctPLS(R, dtype="float32", algorithm="xcov")
+    one.fit(blocks, y)
+    assert seen == [(64 * 64, True, 1.0 / len(blocks))] * (R - 1)
+    monkeypatch.setattr(NipalsEngine, "xcov_one_read", False)
+    two = api.ctPLS(R, dtype="float32", algorithm="xcov")
+    two.fit(blocks, y)
+    assert len(seen) == R - 1 and one.n_iter_ == two.n_iter_
+    assert _normwise(one.factor_T, two.factor_T) <= 1e-10
+    for fs, gs in zip(one.Xs_factors, two.Xs_factors):
+        for f, g in zip(fs[1:], gs[1:]):
+            assert _normwise(f, g) <= 1e-10
+    for r1, r2 in zip(one.R2Xs, two.R2Xs):
+        assert_allclose(r1, r2, rtol=0, atol=1e-11)
+    assert_allclose(one.R2Y, two.R2Y, rtol=0, atol=1e-11)
+    fit = O.fit_ctpls(blocks, y, R)
+    assert one.n_iter_ == fit.n_iter
+    assert _normwise(one.factor_T, fit.T) <= 1e-5
