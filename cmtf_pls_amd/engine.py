@@ -134,9 +134,12 @@ class NipalsEngine:
     # ... and, when X is never written anyway, do not centre it either (round 3): the fit runs on the caller's UNCENTRED tensor --
     # no centring pass, no private copy -- with two rank-one corrections (FitRun._finish_xcov_nowrite); False keeps the centred copy
     xcov_raw = True
-    # one block: score and the contraction with that score from ONE read of X, the second read per component replaced by a
-    # P x a matrix-vector product (FitRun._finish_xcov_nowrite); False keeps the two reads (tests compare the two)
+    # the largest block: score and the contraction with the (block-averaged) score from ONE read of it, the second read per component
+    # replaced by a P x a matrix-vector product (FitRun._finish_xcov_nowrite); False keeps the two reads (tests compare the two)
     xcov_one_read = True
+    # blocks WITH missing values, 2 M <= 64: S = X0^T Y and S2 = X0^T (Y * rowscale) from one matrix-core pass with the I x 2M
+    # right-hand side [Y, Y * rowscale] instead of two passes; False builds them one after the other (tests compare the two)
+    xcov_pair_build = True
 
     def __init__(self, backend, comm=None):
         self.be = backend
@@ -569,11 +572,24 @@ class FitRun:
             self.q_prev = be.zeros(M)
         if algorithm == "xcov":
             nb = len(self.blocks)
-            self.S = [be.empty(M, blk.A * blk.B) for blk in self.blocks]
-            # masked blocks: Y^T t needs the per-row rescale P / n_obs(i) of miss_mmodedot folded into Y
-            self.S2 = [be.empty(M, blk.A * blk.B) if blk.has_miss else None for blk in self.blocks]
+            # masked blocks: Y^T t needs the per-row rescale P / n_obs(i) of miss_mmodedot folded into Y -- a second S, built from
+            # Y * rowscale.  2 M <= 64 responses: both come from ONE matrix-core pass over X with [Y, Y * rowscale] as its I x 2M
+            # right-hand side (S and S2 are the two halves of one 2M x P result)
+            self._s_pair = 2 * M <= 64 and bool(getattr(eng, "xcov_pair_build", True))
+            self.S, self.S2, self.S12 = [], [], []
+            for blk in self.blocks:
+                if blk.has_miss and self._s_pair:
+                    both = be.empty(2 * M, blk.A * blk.B)
+                    self.S12.append(both)
+                    self.S.append(both[:M])
+                    self.S2.append(both[M:])
+                else:
+                    self.S12.append(None)
+                    self.S.append(be.empty(M, blk.A * blk.B))
+                    self.S2.append(be.empty(M, blk.A * blk.B) if blk.has_miss else None)
             self.rowscale = [(float(blk.A * blk.B) / blk.rowcnt) if blk.has_miss else None for blk in self.blocks]
-            self.Yw = be.empty(I, M) if any(blk.has_miss for blk in self.blocks) else None
+            any_miss = any(blk.has_miss for blk in self.blocks)
+            self.Yw = be.empty(I, 2 * M if self._s_pair else M) if any_miss else None
             self.Gy = be.empty(M, M)
             self.Tq = be.empty(nb, M)
             self.qx = [be.zeros(M), be.zeros(M)]      # q of the current / next iteration, alternating by parity
@@ -630,6 +646,12 @@ class FitRun:
         for b, blk in enumerate(self.blocks):
             if self._s_ready:
                 break                                             # S was down-dated by the previous finish_component
+            if self.S12[b] is not None:                           # masked block: S and S2 from one pass
+                self.Yw[:, :self.M].copy_(self.Y)
+                torch.mul(self.Y, self.rowscale[b][:, None], out=self.Yw[:, self.M:])
+                be.xcov(self.X2[b], self.Yw, True, out=self.S12[b], mixed=self.mixed)
+                comm.allreduce(self.S12[b])
+                continue
             be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b], mixed=self.mixed)
             comm.allreduce(self.S[b])
             if self.raw:

@@ -318,6 +318,46 @@ def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
     np.testing.assert_allclose(one.coef_[:ncmp, :ncmp], two.coef_[:ncmp, :ncmp], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("coupled", [False, True])
+def test_xcov_masked_blocks_build_both_cross_covariances_in_one_pass(coupled, monkeypatch):
+    """A block with missing values needs S = X0^T Y (contraction) and S2 = X0^T (Y * rowscale) (the masked score's P / n_obs(i)
+    folded into Y): with 2 M <= 64 both are the halves of ONE xcov pass over X with [Y, Y * rowscale]; same fit as two passes."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    rng = np.random.default_rng(9)
+    x = rng.random((40, 6, 5))
+    x[rng.random(x.shape) < 0.2] = np.nan
+    blocks = [x, rng.random((40, 8))] if coupled else [x]         # (the NaN-free block keeps its single S)
+    Y = rng.random((40, 3))
+    passes = {"n": 0, "widths": []}
+    orig = NumpyBackend.xcov
+
+    def counted(self, X2, Yd, *a, **k):
+        passes["n"] += 1
+        passes["widths"].append(Yd.shape[1])
+        return orig(self, X2, Yd, *a, **k)
+    monkeypatch.setattr(NumpyBackend, "xcov", counted)
+
+    def fit(pair):
+        monkeypatch.setattr(NipalsEngine, "xcov_pair_build", pair)
+        passes["n"], passes["widths"] = 0, []
+        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov")
+        m.fit(blocks if coupled else x, Y)
+        return m, passes["n"], set(passes["widths"])
+
+    two, n2, w2 = fit(False)
+    one, n1, w1 = fit(True)
+    assert w2 == {3} and w1 == ({6, 3} if coupled else {6})
+    assert n2 - n1 == 3                                           # one pass less per component for the masked block
+    assert one.n_iter_ == two.n_iter_
+    f1 = ([one.factor_T] + [f for fs in one.Xs_factors for f in fs[1:]]) if coupled else one.X_factors
+    f2 = ([two.factor_T] + [f for fs in two.Xs_factors for f in fs[1:]]) if coupled else two.X_factors
+    for f, g in zip(f1 + list(one.Y_factors), f2 + list(two.Y_factors)):
+        np.testing.assert_allclose(f, g, rtol=1e-12, atol=1e-13)
+    fit_o = O.fit_ctpls(blocks, Y, 3) if coupled else O.fit_tpls(x, Y, 3)
+    assert one.n_iter_ == fit_o.n_iter
+    np.testing.assert_allclose(f1[0], fit_o.T, rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("case", ["tpls3", "tpls4", "matrix", "coupled"])
 def test_one_pass_projection_equals_sequential(case):
     """transform/predict through one MTTKRP + R x R triangular solve == R project-and-deflate passes."""

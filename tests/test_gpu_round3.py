@@ -388,7 +388,7 @@ def test_xcov_on_the_uncentred_tensor_equals_the_centred_form(api, monkeypatch, 
 
 
 def test_xcov_fit_of_a_device_tensor_neither_writes_nor_copies_it(api):
-    """tPLS(algorithm="xcov").fit(X_device): X is read R + 2 times and that is all -- same bits afterwards, and the fit's peak
+    """tPLS(algorithm="xcov").fit(X_device): X is read R + 3 times and that is all -- same bits afterwards, and the fit's peak
     memory stays far below a second copy of X (inputs are never modified, tpls.py:74, without paying for a clone)."""
     from cmtf_pls_amd.synthetic import synthetic_shard_device
     X, Y = synthetic_shard_device((8192, 128, 128), 16, 10, error=0.1, device="cuda:0")          # 537 MB
@@ -544,3 +544,38 @@ def test_xcov_coupled_fit_reads_the_largest_block_once_per_component(api, monkey
     fit = O.fit_ctpls(blocks, y, R)
     assert one.n_iter_ == fit.n_iter
     assert _normwise(one.factor_T, fit.T) <= 1e-5
+
+
+@pytest.mark.parametrize("M", [6, 32, 40])
+def test_xcov_masked_fit_builds_both_cross_covariances_in_one_pass(api, monkeypatch, M):
+    """Blocks with missing values: S = X0^T Y and S2 = X0^T (Y * rowscale) are the halves of ONE matrix-core pass with the I x 2M
+    right-hand side [Y, Y * rowscale] when 2 M <= 64 (M = 40: two passes as before).  Same fit as with two passes; equals the oracle."""
+    from cmtf_pls_amd.backend import HipBackend
+    from cmtf_pls_amd.engine import NipalsEngine
+    R = 4
+    x, y, _ = O.import_synthetic((300, 32, 64), M, 4, error=0.1, seed=23)
+    rng = np.random.default_rng(2)
+    x[rng.random(x.shape) < 0.3] = np.nan
+    x, y = _f32(x), _f32(y)
+    widths = []
+    orig = HipBackend.xcov
+
+    def counted(self, X2, Yd, *a, **k):
+        widths.append(Yd.shape[1])
+        return orig(self, X2, Yd, *a, **k)
+    monkeypatch.setattr(HipBackend, "xcov", counted)
+    one = api.tPLS(R, dtype="float32", algorithm="xcov")
+    one.fit(x, y)
+    assert widths == ([2 * M] * R if 2 * M <= 64 else [M] * (2 * R))
+    monkeypatch.setattr(NipalsEngine, "xcov_pair_build", False)
+    widths.clear()
+    two = api.tPLS(R, dtype="float32", algorithm="xcov")
+    two.fit(x, y)
+    assert widths == [M] * (2 * R)
+    assert one.n_iter_ == two.n_iter_
+    for f, g in zip(one.X_factors + one.Y_factors, two.X_factors + two.Y_factors):
+        assert _normwise(f, g) <= 1e-11
+    fit = O.fit_tpls(x, y, R)
+    assert one.n_iter_ == fit.n_iter
+    assert _normwise(one.X_factors[0], fit.T) <= 1e-5
+    assert_allclose(one.R2Y, fit.r2y, rtol=0, atol=1e-6)
