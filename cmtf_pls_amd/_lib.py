@@ -18,6 +18,7 @@ _P = c_void_p
 SIGNATURES = {
     "cmtfpls_abi_version": (c_int, []),
     "cmtfpls_last_error": (c_char_p, []),
+    "cmtfpls_status_to_host": (c_int, [_P, _P, c_size_t, _P, _P]),
     "cmtfpls_colstats_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "cmtfpls_colstats_f32": (c_int, [_P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_colstats_f64": (c_int, [_P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),

@@ -160,6 +160,44 @@ class HipBackend:
         _lib.check(fn(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
         return S
 
+    def status_snapshot(self, status: torch.Tensor, slot: int):
+        """Enqueue a copy of a few status words to pinned host memory behind the work issued so far (cmtfpls_status_to_host);
+        returns a token for status_wait.  (slot: the caller keeps at most one snapshot per slot in flight.)"""
+        slots = self.__dict__.setdefault("_status_slots", {})
+        ent = slots.get((slot, status.numel()))
+        if ent is None:
+            host, ev = torch.empty(status.numel(), dtype=torch.float64, pin_memory=True), torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))               # (creates the underlying hipEvent_t)
+            ent = slots[(slot, status.numel())] = (host, ev, host.numpy(), host.data_ptr(), ev.cuda_event, status.numel() * 8)
+        rc = self.lib.cmtfpls_status_to_host(status.data_ptr(), ent[3], ent[5], ent[4], self._stream())
+        if rc:
+            _lib.check(rc, "status_to_host")
+        return ent
+
+    def status_wait(self, token) -> "np.ndarray":
+        token[1].synchronize()
+        return token[2]
+
+    def xcov_iterate_plan(self, S: torch.Tensor, A: int, B: int, q_cur: torch.Tensor, Z: torch.Tensor, wA: torch.Tensor,
+                          wB: torch.Tensor, status: torch.Tensor, q_new: torch.Tensor, G: torch.Tensor):
+        """xcov_iterate on fixed buffers with its arguments marshalled ONCE: returns enqueue(n_squarings, first).  (The inner
+        loop on S is ~15 launches of a few microseconds; per-call argument handling in Python was a tenth of an iteration.)"""
+        M, P = S.shape
+        wc = self._workspace("contract", self.lib.cmtfpls_mode0_contract_workspace_bytes(M, P))
+        wr = self._workspace("rank1", self.lib.cmtfpls_rank1_workspace_bytes(A, B))
+        keep = (S, q_cur, Z, wA, wB, status, q_new, G, wc, wr)                 # the plan owns references: pointers stay valid
+        fn = self.lib.cmtfpls_xcov_iterate_f64
+        head = (_ptr(S), M, A, B, _ptr(q_cur), _ptr(Z), _ptr(wA), _ptr(wB), status[1:3].data_ptr())
+        tail = (_ptr(wc), wc.numel(), _ptr(wr), wr.numel())
+        qn, Gp, du2 = _ptr(q_new), _ptr(G), status[0:1].data_ptr()
+        stream = self._stream
+
+        def enqueue(n_squarings: int, first: bool, _keep=keep) -> None:
+            rc = fn(*head, n_squarings, qn, Gp, du2, 1 if first else 0, *tail, stream())
+            if rc:
+                _lib.check(rc, "xcov_iterate")
+        return enqueue
+
     def xcov_iterate(self, S: torch.Tensor, A: int, B: int, q_cur: torch.Tensor, Z: torch.Tensor, wA: torch.Tensor,
                      wB: torch.Tensor, info: torch.Tensor, n_squarings: int, q_new: torch.Tensor, G: torch.Tensor,
                      du2: torch.Tensor, first: bool) -> None:

@@ -24,4 +24,13 @@ int check_launch(const char* what) {
 extern "C" {
 int cmtfpls_abi_version(void) { return 1; }
 const char* cmtfpls_last_error(void) { return cmtfpls::g_err; }
+
+int cmtfpls_status_to_host(const void* src, void* dst_host, size_t bytes, void* event, void* stream) {
+  if (!src || !dst_host || bytes == 0) { cmtfpls::set_error("status_to_host: bad argument"); return CMTFPLS_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && event) e = hipEventRecord((hipEvent_t)event, st);
+  if (e != hipSuccess) { cmtfpls::set_error(hipGetErrorString(e)); return CMTFPLS_EHIP; }
+  return CMTFPLS_OK;
+}
 }

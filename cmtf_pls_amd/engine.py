@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -140,6 +141,10 @@ class NipalsEngine:
     # blocks WITH missing values, 2 M <= 64: S = X0^T Y and S2 = X0^T (Y * rowscale) from one matrix-core pass with the I x 2M
     # right-hand side [Y, Y * rowscale] instead of two passes; False builds them one after the other (tests compare the two)
     xcov_pair_build = True
+    # the inner loop on S (one NaN-free order-3 block): iteration it + 1 is ENQUEUED before the host has seen iteration it's
+    # convergence norm, into a second set of buffers -- the GPU no longer idles through the status copy, the host's wake-up and
+    # the next launches (FitRun._inner_loop_xcov_pipelined); False waits after every iteration (tests compare the two bit for bit)
+    xcov_pipeline = True
 
     def __init__(self, backend, comm=None):
         self.be = backend
@@ -249,12 +254,7 @@ class NipalsEngine:
             run.mixed = bool(mixed)
             for a in range(n_components):
                 run.start_component(a)
-                for it in range(max_iter):                           # tpls.py:79
-                    du = run.iterate(it)
-                    if du is not None and du < tol:                  # tpls.py:103 (first pass: oldU = inf)
-                        if verbose:
-                            print("Comp {}: converged after {} iterations".format(a, it))
-                        break
+                run.inner_loop(a, max_iter, tol, verbose)            # tpls.py:79-107
                 run.finish_component(a)
             return run.result()
 
@@ -719,6 +719,113 @@ class FitRun:
         else:
             self.qc.copy_(self.qn)               # fixed buffers (a captured graph holds their addresses)
         return None if it == 0 else math.sqrt(max(float(host[0]), 0.0))
+
+    def inner_loop(self, a: int, max_iter: int, tol: float, verbose: int = 0) -> None:
+        """The NIPALS iterations of component a (tpls.py:79-107): iterate until |u_old - u| < tol or max_iter."""
+        if self._pipeline_ok():
+            self._inner_loop_xcov_pipelined(a, max_iter, tol, verbose)
+            return
+        for it in range(max_iter):                                   # tpls.py:79
+            du = self.iterate(it)
+            if du is not None and du < tol:                          # tpls.py:103 (first pass: oldU = inf)
+                if verbose:
+                    print("Comp {}: converged after {} iterations".format(a, it))
+                break
+
+    def _pipeline_ok(self) -> bool:
+        be = self.eng.be
+        if self.algorithm != "xcov" or self.use_graphs or not bool(getattr(self.eng, "xcov_pipeline", False)):
+            return False
+        blk0 = self.blocks[0]
+        return (len(self.blocks) == 1 and len(blk0.shape) == 3 and not blk0.has_miss and self.M <= 64
+                and self.qn.data_ptr() == self.Tq.data_ptr()
+                and all(hasattr(be, f) for f in ("xcov_iterate", "status_snapshot", "status_wait")))
+
+    def _inner_loop_xcov_pipelined(self, a: int, max_iter: int, tol: float, verbose: int) -> None:
+        """The inner loop on S with iteration it + 1 in flight while the host looks at iteration it.
+
+        An iteration on S is ~15 dependent launches of a few microseconds each; waiting for its convergence norm (device ->
+        host copy, wake-up, the next launches) left the GPU idle for a quarter of it.  Iteration it + 1 only needs q of
+        iteration it, which is on the device: it is enqueued right behind iteration it, writing a SECOND set of buffers
+        (Z, wA, wB, status: sets alternate with it; q rotates through three buffers so that a tail that has to be redone
+        still finds its q_cur).  If iteration it turns out to have converged, set it & 1 holds the result and the
+        speculative iteration ran for nothing -- so none is enqueued when the last two norms predict convergence.  Same
+        kernels on the same data in the same order as the waiting loop: bit-identical results, identical iteration counts."""
+        be = self.eng.be
+        blk0 = self.blocks[0]
+        pp = getattr(self, "_pipe", None)
+        if pp is None:
+            M = self.M
+            pp = self._pipe = {
+                "q": [self.qx[0], self.qx[1], be.zeros(M)],
+                "Z": [self.Zs[0], be.empty(blk0.A * blk0.B)],
+                "wA": [self.wA[0], be.empty(blk0.A)],
+                "wB": [self.wB[0], be.empty(blk0.B)],
+                "status": [be.zeros(3), be.zeros(3)],
+            }
+
+        plans = pp.setdefault("plans", {})
+
+        def enqueue(it: int, first: bool = True):
+            s = it & 1
+            st = pp["status"][s]
+            # the first iteration of a component starts from u = Y[:, 0] (tpls.py:78): its Z has another spectrum than the last
+            # iterations of the previous component, whose need the budget remembers -- 4 spare launches (~4 us each when unused)
+            # instead of a tail redone in every other component
+            nsq = self.sq_budget[0] if it > 0 else min(self.sq_max, self.sq_budget[0] + 4)
+            if hasattr(be, "xcov_iterate_plan"):                     # arguments marshalled once per (set, q rotation)
+                plan = plans.get(it % 6)
+                if plan is None:
+                    plan = plans[it % 6] = be.xcov_iterate_plan(self.S[0], blk0.A, blk0.B, pp["q"][it % 3], pp["Z"][s], pp["wA"][s],
+                                                                pp["wB"][s], st, pp["q"][(it + 1) % 3], self.Gy)
+                plan(nsq, first)
+            else:
+                be.xcov_iterate(self.S[0], blk0.A, blk0.B, pp["q"][it % 3], pp["Z"][s], pp["wA"][s], pp["wB"][s], st[1:3],
+                                nsq, pp["q"][(it + 1) % 3], self.Gy, st[0:1], first)
+            return be.status_snapshot(st, s)
+
+        stats = self.eng.__dict__.setdefault("pipeline_stats", {"iterations": 0, "ahead": 0, "unused": 0, "waited": 0, "redone": 0})
+        it, tok = 0, enqueue(0)
+        du_prev = du = None
+        while True:
+            ahead = None
+            if it + 1 < max_iter:
+                # |du| shrinks geometrically: no speculation when the next norm is predicted below tol (the wait costs less
+                # than an iteration run for nothing)
+                predicted = None if (du is None or du_prev is None or du_prev <= 0.0) else du * (du / du_prev)
+                if it == 0 or predicted is None or predicted >= tol:
+                    ahead = enqueue(it + 1)
+                    stats["ahead"] += 1
+            host = be.status_wait(tok)
+            conv, used = host[1] > 0.5, int(host[2])
+            if not conv and self.sq_budget[0] < self.sq_max:
+                # the rank-1 extraction ran out of squarings: redo the tail of iteration it with the full budget (Z of set
+                # it & 1 is intact; whatever was enqueued ahead was built on the unfinished loadings and is overwritten later)
+                self.sq_budget[0] = self.sq_max
+                tok = enqueue(it, first=False)
+                stats["redone"] += 1
+                if os.environ.get("CMTFPLS_PIPELINE_DEBUG"):
+                    print(f"  pipeline: component {a} iteration {it} redone (used {used})", flush=True)
+                continue
+            if conv:
+                self.sq_budget[0] = min(self.sq_max, used + 1)
+            self._executed += 1
+            stats["iterations"] += 1
+            du_prev, du = du, (None if it == 0 else math.sqrt(max(float(host[0]), 0.0)))
+            if (du is not None and du < tol) or it + 1 >= max_iter:  # tpls.py:103 (first pass: oldU = inf)
+                if verbose and du is not None and du < tol:
+                    print("Comp {}: converged after {} iterations".format(a, it))
+                stats["unused"] += ahead is not None                  # an iteration that ran for nothing
+                break
+            it += 1
+            stats["waited"] += ahead is None                         # the GPU idled through one host round trip
+            tok = ahead if ahead is not None else enqueue(it)
+        s = it & 1
+        if s == 1:                                                   # the engine's own buffers are set 0
+            self.wA[0].copy_(pp["wA"][1])
+            self.wB[0].copy_(pp["wB"][1])
+        self.qc = pp["q"][(it + 1) % 3]
+        self._parity = 0
 
     def _update_budgets(self, host) -> bool:
         """Adapt the squaring budget of every order-3 block; True if the iteration tail must be redone."""

@@ -38,6 +38,10 @@ extern "C" {
 
 int cmtfpls_abi_version(void);
 const char* cmtfpls_last_error(void);
+/* A few status words (convergence norm, rank-1 flags) to PINNED host memory behind the work enqueued so far, then `event`
+ * (a hipEvent_t, nullable) recorded: what the host waits on once per NIPALS iteration (tpls.py:103-107) -- one call instead
+ * of a framework copy + record, because the pipelined inner loop (engine.FitRun._inner_loop_xcov_pipelined) is bound by host time. */
+int cmtfpls_status_to_host(const void* src, void* dst_host, size_t bytes, void* event, void* stream);
 
 /* ---- preprocess: tpls.py:61-71, cmtf.py:74-83 ------------------------------------------------
  * colstats: colsum[c] = sum over non-NaN i of X[i,c]; colcnt[c] = number of non-NaN i

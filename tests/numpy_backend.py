@@ -97,6 +97,12 @@ class NumpyBackend:
         self.score(S, A, B, wA, wB, None, q_new)
         self.q_update(q_new, None, True, G, q_cur, du2)
 
+    def status_snapshot(self, status, slot):
+        return status.clone().numpy()
+
+    def status_wait(self, token):
+        return token
+
     def kr_axpy(self, v, A, B, WA, WB, k, coef):
         W = (_np(WA)[:, None, :k] * _np(WB)[None, :, :k]).reshape(A * B, k)
         vv = _np(v)

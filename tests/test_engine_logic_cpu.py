@@ -318,6 +318,52 @@ def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
     np.testing.assert_allclose(one.coef_[:ncmp, :ncmp], two.coef_[:ncmp, :ncmp], rtol=1e-8, atol=1e-10)
 
 
+class _StingyBackend(NumpyBackend):
+    """A rank-1 extraction that fails (garbage loadings, convergence flag 0) whenever it is given fewer squarings than the maximum:
+    every iteration after the first has to redo its tail -- the retry path of both inner loops."""
+    retries = 0
+
+    def rank1(self, Z, A, B, wA, wB, info=None, n_squarings=None):
+        if n_squarings is not None and n_squarings < self.rank1_squarings:
+            type(self).retries += 1
+            wA.fill_(float("nan"))
+            wB.fill_(float("nan"))
+            info[0], info[1] = 0.0, float(n_squarings)
+            return
+        super().rank1(Z, A, B, wA, wB, info=info, n_squarings=n_squarings)
+        info[1] = 3.0                                             # "3 squarings were enough": the next budget is 4 < max
+
+
+@pytest.mark.parametrize("backend", [NumpyBackend, _StingyBackend])
+@pytest.mark.parametrize("max_iter", [100, 1, 2, 5])
+def test_xcov_pipelined_inner_loop_is_bit_identical_to_the_waiting_loop(backend, max_iter, monkeypatch):
+    """FitRun._inner_loop_xcov_pipelined enqueues iteration it + 1 before the host has seen iteration it's norm (second buffer
+    set, three q buffers): same kernels on the same data in the same order as the loop that waits after every iteration --
+    identical bits, identical iteration counts, also when max_iter cuts the loop and when tails have to be redone."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    x, y, _ = O.import_synthetic((60, 9, 7), 4, 3, error=0.3, seed=11)
+
+    def fit(pipeline):
+        monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
+        backend.retries = 0
+        m = tPLS(4, backend=backend(), algorithm="xcov")
+        m.fit(x, y, max_iter=max_iter)
+        return m, backend.retries
+
+    wait, r_wait = fit(False)
+    pipe, r_pipe = fit(True)
+    assert pipe.n_iter_ == wait.n_iter_ and max(wait.n_iter_) <= max_iter
+    if backend is _StingyBackend and max_iter > 1:
+        assert r_wait > 0 and r_pipe > 0                          # (how many differs: the pipelined budget is one iteration older)
+    for f, g in zip(pipe.X_factors + pipe.Y_factors, wait.X_factors + wait.Y_factors):
+        assert np.array_equal(f, g)
+    assert np.array_equal(pipe.coef_, wait.coef_) and np.array_equal(pipe.R2X, wait.R2X) and np.array_equal(pipe.R2Y, wait.R2Y)
+    if max_iter == 100:
+        ref = O.fit_tpls(x, y, 4)
+        assert pipe.n_iter_ == ref.n_iter
+        np.testing.assert_allclose(pipe.X_factors[0], ref.T, rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("coupled", [False, True])
 def test_xcov_masked_blocks_build_both_cross_covariances_in_one_pass(coupled, monkeypatch):
     """A block with missing values needs S = X0^T Y (contraction) and S2 = X0^T (Y * rowscale) (the masked score's P / n_obs(i)

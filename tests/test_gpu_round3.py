@@ -579,3 +579,27 @@ def test_xcov_masked_fit_builds_both_cross_covariances_in_one_pass(api, monkeypa
     assert one.n_iter_ == fit.n_iter
     assert _normwise(one.X_factors[0], fit.T) <= 1e-5
     assert_allclose(one.R2Y, fit.r2y, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,dtype", [((400, 128, 128), "float32"), ((300, 24, 32), "float64"), ((500, 40, 200), "float32")])
+def test_xcov_pipelined_inner_loop_is_bit_identical_to_the_waiting_loop(api, monkeypatch, shape, dtype):
+    """The inner loop on S with iteration it + 1 enqueued before the host has seen iteration it's convergence norm (second buffer
+    set; FitRun._inner_loop_xcov_pipelined): the same kernels on the same data in the same order as the loop that waits after
+    every iteration -- identical bits and iteration counts; `max_iter` cutting the loop included."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    x, y, _ = O.import_synthetic(shape, 6, 5, error=0.2, seed=29)
+    if dtype == "float32":
+        x, y = _f32(x), _f32(y)
+    for max_iter in (100, 3):
+        fits = []
+        for pipeline in (False, True):
+            monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
+            m = api.tPLS(5, dtype=dtype, algorithm="xcov")
+            m.fit(x, y, max_iter=max_iter)
+            fits.append(m)
+        wait, pipe = fits
+        assert pipe.n_iter_ == wait.n_iter_
+        for f, g in zip(pipe.X_factors + pipe.Y_factors, wait.X_factors + wait.Y_factors):
+            assert np.array_equal(f, g)
+        assert np.array_equal(pipe.coef_, wait.coef_) and np.array_equal(pipe.R2X, wait.R2X) and np.array_equal(pipe.R2Y, wait.R2Y)
+    assert pipe.n_iter_ == [3] * 5 or max(pipe.n_iter_) <= 3

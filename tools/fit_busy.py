@@ -13,6 +13,8 @@ algo = sys.argv[1] if len(sys.argv) > 1 else "xcov"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 if len(sys.argv) > 3 and sys.argv[3] == "two":
     NipalsEngine.xcov_one_read = False
+if os.environ.get("CMTFPLS_NO_PIPELINE"):      # A/B of the pipelined inner loop
+    NipalsEngine.xcov_pipeline = False
 dev = torch.device("cuda:0")
 eng = NipalsEngine(HipBackend(dev), None)
 f64 = len(sys.argv) > 4 and sys.argv[4] == "f64"          # f64 storage: half the rows, the same bytes
@@ -27,4 +29,6 @@ for i in range(N + 1):
     st = eng.fit([Xf], Yf, 10, tol=1e-8, max_iter=100, coupled=False, algorithm=algo)
     torch.cuda.synchronize()
     walls.append(time.perf_counter() - t0)
+if getattr(eng, "pipeline_stats", None):
+    print("pipelined inner loop, all fits:", eng.pipeline_stats, flush=True)
 print(f"{algo}: first {walls[0]*1e3:.2f} ms, then {[round(w*1e3, 2) for w in walls[1:]]} ms per fit, {sum(st.n_iter)} iterations, {N + 1} fits in all", flush=True)
