@@ -626,8 +626,6 @@ class FitRun:
                         self.ps = be.empty(P0)
                         self.Rm = be.zeros(P0, R)                                # column j: X_0^T t_j
                         self.corr = be.empty(I)
-                        self.minus_one = be.empty(1)
-                        self.minus_one.fill_(-1.0)
             assert self._nowrite or not self.raw, "an uncentred X needs the form of the loop that never writes it"
 
     def start_component(self, a: int) -> None:
@@ -1273,7 +1271,7 @@ class FitRun:
         Ta = self.T[:, :k]
         ya = be.gram_tn(self.Y, self.t).reshape(-1)                              # Y^T t with the not yet deflated Y
         b_dev, ya_g = self._inner_regression(a, extra=ya)                        # tpls.py:110-112; ya_g: all-reduced Y^T t
-        if k < R:
+        if k < R and not (one_read and nb == 1):                                 # (the fused block needs no yhat: X_0^T yhat = Rm b)
             be.rowdot(Ta, b_dev, self.yhat.view(-1), None)                       # yhat = T b (what Y is deflated by)
         ssqy = be.y_deflate(self.Y, self.T, k, b_dev, self.q)                    # tpls.py:113
         if k < R:
@@ -1281,8 +1279,7 @@ class FitRun:
             for b, blk in enumerate(self.blocks):
                 WA, WB = self.eng._kr_operands(blk, R)                           # columns <= a: the components so far
                 if one_read and b == fused_b:                                    # X_0^T yhat = sum_j b_j (X_0^T t_j): no read of X
-                    self.vs[b].zero_()
-                    be.y_deflate(self.vs[b].view(-1, 1), self.Rm, k, b_dev, self.minus_one)
+                    be.rowdot(self.Rm[:, :k], b_dev, self.vs[b], None)
                 else:
                     be.mode0_contract(self.X2[b], self.yhat.view(-1), False, out=self.vs[b])   # X_0^T yhat
                     comm.allreduce(self.vs[b])
