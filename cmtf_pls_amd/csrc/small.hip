@@ -238,6 +238,20 @@ __global__ __launch_bounds__(256) void s_downdate_kernel(double* __restrict__ S,
   }
 }
 
+// Z[c] = sum_m q[m] S[m, c]: np.einsum("i...,i->...", X, u) (tpls.py:83) re-associated through S = Y^T X_(0) with u = Y q.
+// S has M <= 64 rows and lives in L2: one thread per column, the M rows in index order (one fixed fma chain per column), no
+// partial rows and no second kernel -- the general contraction (sweeps.hip) splits rows over workgroups and adds a
+// reduce_rows launch, one launch of pure latency too many in an iteration that is ~14 of them.
+__global__ __launch_bounds__(256) void s_contract_kernel(const double* __restrict__ S, int M, int64_t P, const double* __restrict__ q,
+                                                        double* __restrict__ Z) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= P) return;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int m = 0; m < M; ++m) acc = fma(q[m], S[(int64_t)m * P + c], acc);
+  Z[c] = acc;
+}
+
 // y[i] -= a[0] * (x ? x[i] : 1): the two rank-one corrections of the cross-covariance loop on an UNCENTRED X (round 3):
 //   X_c w = X w - (mean^T w) 1   (a scalar shift of the I scores),   X_c^T yhat = X^T yhat - (1^T yhat) mean   (P entries).
 __global__ __launch_bounds__(256) void axpy_scalar_kernel(double* __restrict__ y, int64_t n, const double* __restrict__ a,
@@ -394,7 +408,10 @@ int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double*
   if (M > 64) { set_error("xcov_iterate: more than 64 responses"); return CMTFPLS_EUNSUPPORTED; }
   const int64_t P = (int64_t)A * B;
   int rc = CMTFPLS_OK;
-  if (first) rc = cmtfpls_mode0_contract_f64(S, M, P, q_cur, Z, 0, ws_contract, ws_contract_bytes, stream);   // Z = sum_m q_m S_m
+  if (first) {                                                                                                // Z = sum_m q_m S_m
+    hipLaunchKernelGGL(s_contract_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, M, P, q_cur, Z);
+    rc = check_launch("xcov_iterate: s_contract");
+  }
   if (rc == CMTFPLS_OK) rc = cmtfpls_rank1_f64(Z, A, B, wA, wB, nullptr, info, n_squarings, ws_rank1, ws_rank1_bytes, stream);
   if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(S, M, A, B, wA, wB, nullptr, q_new, stream);                   // Y^T t = S (wA (x) wB)
   if (rc == CMTFPLS_OK) rc = cmtfpls_q_update_f64(nullptr, 0, M, q_new, 1, G, q_cur, du2, stream);            // / norm, |du|^2
