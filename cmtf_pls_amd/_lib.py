@@ -14,8 +14,15 @@ LIB_PATH = os.environ.get("CMTFPLS_LIB") or os.path.join(_HERE, "lib", "libcmtfp
 
 _P = c_void_p
 
+class XcovBlock(ctypes.Structure):
+    """cmtfpls_xcov_block (include/cmtfpls.h): one block of cmtfpls_xcov_iterate_blocks_f64."""
+    _fields_ = [("S", _P), ("S2", _P), ("colcnt", _P), ("n_samples", c_double), ("order", c_int), ("A", c_int), ("B", c_int),
+                ("n_squarings", c_int), ("Z", _P), ("wA", _P), ("wB", _P), ("info", _P)]
+
+
 # name -> (restype, argtypes); mirrors include/cmtfpls.h one to one
 SIGNATURES = {
+    "cmtfpls_xcov_iterate_blocks_f64": (c_int, [ctypes.POINTER(XcovBlock), c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_abi_version": (c_int, []),
     "cmtfpls_last_error": (c_char_p, []),
     "cmtfpls_status_to_host": (c_int, [_P, _P, c_size_t, _P, _P]),

@@ -209,6 +209,40 @@ class HipBackend:
                                                      int(n_squarings), _ptr(q_new), _ptr(G), _ptr(du2), int(first),
                                                      _ptr(wc), wc.numel(), _ptr(wr), wr.numel(), self._stream()), "xcov_iterate")
 
+    def xcov_blocks_plan(self, blocks, M: int, q_cur: torch.Tensor, tq: torch.Tensor, q_new: torch.Tensor, G: torch.Tensor,
+                         status: torch.Tensor):
+        """One inner iteration on S for SEVERAL coupled blocks / blocks with missing values (cmtfpls_xcov_iterate_blocks_f64) on fixed
+        buffers, arguments marshalled once.  blocks: dicts with S, S2 (or None), colcnt (or None), n_samples, order (2 | 3), A, B,
+        Z, wA, wB; status = [du2, (converged, squarings used) per block].  Returns enqueue(n_squarings per block, first), or
+        None when a block is outside the entry (order > 3, M > 64)."""
+        nb = len(blocks)
+        if M > 64 or any(b["order"] not in (2, 3) for b in blocks) or tq.numel() != nb * M or not tq.is_contiguous():
+            return None
+        arr = (_lib.XcovBlock * nb)()
+        need = 256
+        for i, b in enumerate(blocks):
+            for name in ("S", "S2", "colcnt", "Z", "wA", "wB"):
+                t = b.get(name)
+                assert t is None or (t.is_contiguous() and t.dtype == torch.float64 and t.device == self.device), name
+                setattr(arr[i], name, _ptr(t))
+            arr[i].n_samples, arr[i].order, arr[i].A, arr[i].B = float(b["n_samples"]), int(b["order"]), int(b["A"]), int(b["B"])
+            arr[i].info = status[1 + 2 * i: 3 + 2 * i].data_ptr()
+            if b["order"] == 3:
+                need = max(need, self.lib.cmtfpls_rank1_workspace_bytes(b["A"], b["B"]))
+        wr = self._workspace("rank1", need)
+        keep = (blocks, q_cur, tq, q_new, G, status, wr, arr)                    # the plan owns references: pointers stay valid
+        fn, stream = self.lib.cmtfpls_xcov_iterate_blocks_f64, self._stream
+        args = (nb, M, _ptr(q_cur), _ptr(tq), _ptr(q_new), _ptr(G), status[0:1].data_ptr())
+        tail = (_ptr(wr), wr.numel())
+
+        def enqueue(n_squarings, first: bool, _keep=keep) -> None:
+            for i in range(nb):
+                arr[i].n_squarings = int(n_squarings[i])
+            rc = fn(arr, *args, 1 if first else 0, *tail, stream())
+            if rc:
+                _lib.check(rc, "xcov_iterate_blocks")
+        return enqueue
+
     def s_downdate(self, S: torch.Tensor, A: int, B: int, ya: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
                    q: torch.Tensor, v: torch.Tensor) -> None:
         """S -= ya w^T + q v^T, w = kron(wA, wB): S = Y^T X_(0) carried across one deflation."""

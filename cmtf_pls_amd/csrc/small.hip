@@ -151,6 +151,15 @@ __global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ v,
   if (nrm && threadIdx.x == 0) nrm[0] = s;
 }
 
+// out = in / ||in||_2 : one workgroup (normalize_kernel with the copy folded in: the loading of a matrix block, tpls.py:84-90 for a vector Z)
+__global__ __launch_bounds__(1024) void normalize_to_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s = fma(in[i], in[i], s);
+  s = sqrt(block_sum(s, red));
+  for (int64_t i = threadIdx.x; i < n; i += 1024) out[i] = in[i] / s;
+}
+
 // The Y-side update of one NIPALS iteration in one workgroup (tpls.py:100-103):
 //   q <- sum over workgroups of qpart (the score kernel's partial sums of Y^T t)      [qpart != null]
 //   q <- q / |q|                                                                      [normalize]
@@ -415,6 +424,39 @@ int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double*
   if (rc == CMTFPLS_OK) rc = cmtfpls_rank1_f64(Z, A, B, wA, wB, nullptr, info, n_squarings, ws_rank1, ws_rank1_bytes, stream);
   if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(S, M, A, B, wA, wB, nullptr, q_new, stream);                   // Y^T t = S (wA (x) wB)
   if (rc == CMTFPLS_OK) rc = cmtfpls_q_update_f64(nullptr, 0, M, q_new, 1, G, q_cur, du2, stream);            // / norm, |du|^2
+  return rc;
+}
+
+int cmtfpls_xcov_iterate_blocks_f64(const cmtfpls_xcov_block* blocks, int nb, int M, const double* q_cur, double* tq, double* q_new,
+                                    const double* G, double* du2, int first, void* ws_rank1, size_t ws_rank1_bytes, void* stream) {
+  if (!blocks || nb <= 0 || !q_cur || !tq || !q_new || !G || !du2 || M <= 0) { set_error("xcov_iterate_blocks: bad argument"); return CMTFPLS_EINVAL; }
+  if (M > 64) { set_error("xcov_iterate_blocks: more than 64 responses"); return CMTFPLS_EUNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = CMTFPLS_OK;
+  for (int b = 0; b < nb && rc == CMTFPLS_OK; ++b) {
+    const cmtfpls_xcov_block& k = blocks[b];
+    if (!k.S || !k.Z || !k.wA || !k.wB || k.A <= 0 || k.B <= 0 || (k.order != 2 && k.order != 3) || (k.order == 2 && k.A != 1) ||
+        (k.order == 3 && !k.info)) {
+      set_error("xcov_iterate_blocks: bad block");
+      return CMTFPLS_EINVAL;
+    }
+    const int64_t P = (int64_t)k.A * k.B;
+    if (first) {
+      hipLaunchKernelGGL(s_contract_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, k.S, M, P, q_cur, k.Z);   // cmtf.py:94
+      rc = check_launch("xcov_iterate_blocks: s_contract");
+      if (rc == CMTFPLS_OK && k.colcnt) rc = cmtfpls_colscale_f64(k.Z, P, k.colcnt, k.n_samples, stream);             // missingvals.py:17-19
+    }
+    if (rc != CMTFPLS_OK) break;
+    if (k.order == 3) {
+      rc = cmtfpls_rank1_f64(k.Z, k.A, k.B, k.wA, k.wB, nullptr, k.info, k.n_squarings, ws_rank1, ws_rank1_bytes, stream);   // cmtf.py:98-104
+    } else {
+      hipLaunchKernelGGL(normalize_to_kernel, dim3(1), dim3(1024), 0, st, k.Z, k.wB, P);
+      rc = check_launch("xcov_iterate_blocks: normalize_to");
+    }
+    if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(k.S2 ? k.S2 : k.S, M, k.A, k.B, k.wA, k.wB, nullptr, tq + (int64_t)b * M, stream);   // cmtf.py:106-119
+  }
+  if (rc == CMTFPLS_OK && (nb > 1 || q_new != tq)) rc = cmtfpls_scores_mean_f64(tq, nb, M, q_new, stream);            // cmtf.py:120
+  if (rc == CMTFPLS_OK) rc = cmtfpls_q_update_f64(nullptr, 0, M, q_new, 1, G, q_cur, du2, stream);                   // cmtf.py:121-125
   return rc;
 }
 

@@ -730,57 +730,78 @@ class FitRun:
                     print("Comp {}: converged after {} iterations".format(a, it))
                 break
 
+    def _single_composite(self) -> bool:
+        blk0 = self.blocks[0]
+        return (len(self.blocks) == 1 and len(blk0.shape) == 3 and not blk0.has_miss and self.M <= 64
+                and self.qn.data_ptr() == self.Tq.data_ptr() and hasattr(self.eng.be, "xcov_iterate"))
+
     def _pipeline_ok(self) -> bool:
         be = self.eng.be
         if self.algorithm != "xcov" or self.use_graphs or not bool(getattr(self.eng, "xcov_pipeline", False)):
             return False
-        blk0 = self.blocks[0]
-        return (len(self.blocks) == 1 and len(blk0.shape) == 3 and not blk0.has_miss and self.M <= 64
-                and self.qn.data_ptr() == self.Tq.data_ptr()
-                and all(hasattr(be, f) for f in ("xcov_iterate", "status_snapshot", "status_wait")))
+        if self.M > 64 or not all(hasattr(be, f) for f in ("status_snapshot", "status_wait")):
+            return False
+        return self._single_composite() or (hasattr(be, "xcov_blocks_plan") and all(len(blk.shape) in (2, 3) for blk in self.blocks))
 
     def _inner_loop_xcov_pipelined(self, a: int, max_iter: int, tol: float, verbose: int) -> None:
         """The inner loop on S with iteration it + 1 in flight while the host looks at iteration it.
 
-        An iteration on S is ~15 dependent launches of a few microseconds each; waiting for its convergence norm (device ->
-        host copy, wake-up, the next launches) left the GPU idle for a quarter of it.  Iteration it + 1 only needs q of
-        iteration it, which is on the device: it is enqueued right behind iteration it, writing a SECOND set of buffers
-        (Z, wA, wB, status: sets alternate with it; q rotates through three buffers so that a tail that has to be redone
-        still finds its q_cur).  If iteration it turns out to have converged, set it & 1 holds the result and the
-        speculative iteration ran for nothing -- so none is enqueued when the last two norms predict convergence.  Same
-        kernels on the same data in the same order as the waiting loop: bit-identical results, identical iteration counts."""
+        An iteration on S is ~15 dependent launches of a few microseconds each (per order-3 block); waiting for its
+        convergence norm (device -> host copy, wake-up, the next launches) left the GPU idle for a quarter of it.  Iteration
+        it + 1 only needs q of iteration it, which is on the device: it is enqueued right behind iteration it, writing a
+        SECOND set of buffers (Z, wA, wB per block, status: sets alternate with it; q rotates through three buffers so that a
+        tail that has to be redone still finds its q_cur).  If iteration it turns out to have converged, set it & 1 holds the
+        result and the speculative iteration ran for nothing -- so none is enqueued when the last two norms predict
+        convergence.  One host call per iteration with its arguments marshalled once (backend.xcov_iterate_plan for one
+        NaN-free order-3 block, backend.xcov_blocks_plan for coupled blocks / blocks with missing values of order 2 or 3).
+        Same kernels on the same data in the same order as the waiting loop: identical iteration counts, and for the
+        one-block form identical bits."""
         be = self.eng.be
-        blk0 = self.blocks[0]
+        nb = len(self.blocks)
+        single = self._single_composite()
         pp = getattr(self, "_pipe", None)
         if pp is None:
             M = self.M
+            second = {"Z": [], "wA": [], "wB": []}
+            for b, blk in enumerate(self.blocks):
+                second["Z"].append(be.empty(blk.A * blk.B))
+                second["wA"].append(self.wA[b].clone())              # (the constant [1] of a matrix block comes along)
+                second["wB"].append(be.empty(blk.B))
             pp = self._pipe = {
                 "q": [self.qx[0], self.qx[1], be.zeros(M)],
-                "Z": [self.Zs[0], be.empty(blk0.A * blk0.B)],
-                "wA": [self.wA[0], be.empty(blk0.A)],
-                "wB": [self.wB[0], be.empty(blk0.B)],
-                "status": [be.zeros(3), be.zeros(3)],
+                "Z": [list(self.Zs), second["Z"]], "wA": [list(self.wA), second["wA"]], "wB": [list(self.wB), second["wB"]],
+                "status": [be.zeros(1 + 2 * nb), be.zeros(1 + 2 * nb)],
+                "plans": {},
             }
+            for st in pp["status"]:
+                st[1::2] = 1.0                                       # (blocks without a rank-1 chain never write their flag)
+        plans = pp["plans"]
 
-        plans = pp.setdefault("plans", {})
+        def make_plan(it: int):
+            s = it & 1
+            st, q_cur, q_new = pp["status"][s], pp["q"][it % 3], pp["q"][(it + 1) % 3]
+            if single:
+                blk0 = self.blocks[0]
+                if hasattr(be, "xcov_iterate_plan"):                 # arguments marshalled once per (set, q rotation)
+                    one = be.xcov_iterate_plan(self.S[0], blk0.A, blk0.B, q_cur, pp["Z"][s][0], pp["wA"][s][0], pp["wB"][s][0], st,
+                                               q_new, self.Gy)
+                    return lambda nsq, first: one(nsq[0], first)
+                return lambda nsq, first: be.xcov_iterate(self.S[0], blk0.A, blk0.B, q_cur, pp["Z"][s][0], pp["wA"][s][0],
+                                                          pp["wB"][s][0], st[1:3], nsq[0], q_new, self.Gy, st[0:1], first)
+            descr = [dict(S=self.S[b], S2=self.S2[b] if blk.has_miss else None, colcnt=blk.colcnt if blk.has_miss else None,
+                          n_samples=self.n_total, order=len(blk.shape), A=blk.A, B=blk.B,
+                          Z=pp["Z"][s][b], wA=pp["wA"][s][b], wB=pp["wB"][s][b]) for b, blk in enumerate(self.blocks)]
+            return be.xcov_blocks_plan(descr, self.M, q_cur, self.Tq, q_new, self.Gy, st)
 
         def enqueue(it: int, first: bool = True):
-            s = it & 1
-            st = pp["status"][s]
+            plan = plans.get(it % 6)
+            if plan is None:
+                plan = plans[it % 6] = make_plan(it)
             # the first iteration of a component starts from u = Y[:, 0] (tpls.py:78): its Z has another spectrum than the last
             # iterations of the previous component, whose need the budget remembers -- 4 spare launches (~4 us each when unused)
             # instead of a tail redone in every other component
-            nsq = self.sq_budget[0] if it > 0 else min(self.sq_max, self.sq_budget[0] + 4)
-            if hasattr(be, "xcov_iterate_plan"):                     # arguments marshalled once per (set, q rotation)
-                plan = plans.get(it % 6)
-                if plan is None:
-                    plan = plans[it % 6] = be.xcov_iterate_plan(self.S[0], blk0.A, blk0.B, pp["q"][it % 3], pp["Z"][s], pp["wA"][s],
-                                                                pp["wB"][s], st, pp["q"][(it + 1) % 3], self.Gy)
-                plan(nsq, first)
-            else:
-                be.xcov_iterate(self.S[0], blk0.A, blk0.B, pp["q"][it % 3], pp["Z"][s], pp["wA"][s], pp["wB"][s], st[1:3],
-                                nsq, pp["q"][(it + 1) % 3], self.Gy, st[0:1], first)
-            return be.status_snapshot(st, s)
+            plan([n if it > 0 else min(self.sq_max, n + 4) for n in self.sq_budget], first)
+            return be.status_snapshot(pp["status"][it & 1], it & 1)
 
         stats = self.eng.__dict__.setdefault("pipeline_stats", {"iterations": 0, "ahead": 0, "unused": 0, "waited": 0, "redone": 0})
         it, tok = 0, enqueue(0)
@@ -795,18 +816,20 @@ class FitRun:
                     ahead = enqueue(it + 1)
                     stats["ahead"] += 1
             host = be.status_wait(tok)
-            conv, used = host[1] > 0.5, int(host[2])
-            if not conv and self.sq_budget[0] < self.sq_max:
-                # the rank-1 extraction ran out of squarings: redo the tail of iteration it with the full budget (Z of set
-                # it & 1 is intact; whatever was enqueued ahead was built on the unfinished loadings and is overwritten later)
-                self.sq_budget[0] = self.sq_max
+            short = [b for b in range(nb) if not host[1 + 2 * b] > 0.5 and self.sq_budget[b] < self.sq_max]
+            if short:
+                # a rank-1 extraction ran out of squarings: redo the tail of iteration it with the full budget (Z of set it & 1
+                # is intact; whatever was enqueued ahead was built on the unfinished loadings and is overwritten later)
+                for b in short:
+                    self.sq_budget[b] = self.sq_max
                 tok = enqueue(it, first=False)
                 stats["redone"] += 1
                 if os.environ.get("CMTFPLS_PIPELINE_DEBUG"):
-                    print(f"  pipeline: component {a} iteration {it} redone (used {used})", flush=True)
+                    print(f"  pipeline: component {a} iteration {it} redone (blocks {short})", flush=True)
                 continue
-            if conv:
-                self.sq_budget[0] = min(self.sq_max, used + 1)
+            for b, blk in enumerate(self.blocks):
+                if len(blk.shape) == 3 and host[1 + 2 * b] > 0.5:
+                    self.sq_budget[b] = min(self.sq_max, int(host[2 + 2 * b]) + 1)
             self._executed += 1
             stats["iterations"] += 1
             du_prev, du = du, (None if it == 0 else math.sqrt(max(float(host[0]), 0.0)))
@@ -818,10 +841,10 @@ class FitRun:
             it += 1
             stats["waited"] += ahead is None                         # the GPU idled through one host round trip
             tok = ahead if ahead is not None else enqueue(it)
-        s = it & 1
-        if s == 1:                                                   # the engine's own buffers are set 0
-            self.wA[0].copy_(pp["wA"][1])
-            self.wB[0].copy_(pp["wB"][1])
+        if it & 1:                                                   # the engine's own buffers are set 0
+            for b in range(nb):
+                self.wA[b].copy_(pp["wA"][1][b])
+                self.wB[b].copy_(pp["wB"][1][b])
         self.qc = pp["q"][(it + 1) % 3]
         self._parity = 0
 

@@ -128,6 +128,28 @@ int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double*
                              double* wB, double* info, int n_squarings, double* q_new, const double* G, double* du2,
                              int first, void* ws_contract, size_t ws_contract_bytes, void* ws_rank1,
                              size_t ws_rank1_bytes, void* stream);
+/* The same for SEVERAL coupled blocks and for blocks with missing values (cmtf.py:91-128 re-associated), one host call:
+ * per block  Z_b = sum_m q_cur[m] S_b[m,:]  (first != 0 only; masked blocks: Z_b[c] *= n_samples / colcnt[c], missingvals.py:17-19),
+ * the loading -- rank1(Z_b) for an order-3 block (A x B), Z_b / |Z_b| for a matrix block (order 2: A = 1, wA = [1] is the caller's) --
+ * and tq_b = S2_b (wA (x) wB)  (S2: the cross-covariance with the masked score's row rescale folded into Y; null = S);
+ * then q_new = mean_b tq_b (cmtf.py:120; tq of block b is row b of the nb x M matrix `tq`), normalised, and
+ * du2 = (q_new - q_cur)^T G (q_new - q_cur).  Blocks of order 2 or 3, M <= 64; ws_rank1: the largest
+ * cmtfpls_rank1_workspace_bytes(A, B) of the order-3 blocks. */
+typedef struct {
+  const double* S;        /* M x A*B */
+  const double* S2;       /* M x A*B or null */
+  const double* colcnt;   /* A*B observation counts or null (no missing values) */
+  double n_samples;       /* rows of X over all ranks (used with colcnt) */
+  int order;              /* 2 (matrix block, A == 1) or 3 */
+  int A, B;
+  int n_squarings;        /* order 3 */
+  double* Z;              /* A*B */
+  double* wA;             /* A */
+  double* wB;             /* B */
+  double* info;           /* order 3: {converged, squarings used} */
+} cmtfpls_xcov_block;
+int cmtfpls_xcov_iterate_blocks_f64(const cmtfpls_xcov_block* blocks, int nb, int M, const double* q_cur, double* tq, double* q_new,
+                                    const double* G, double* du2, int first, void* ws_rank1, size_t ws_rank1_bytes, void* stream);
 /* S carried across one deflation instead of rebuilt (tpls.py:109 and :113 applied to S = Y^T X_(0)):
  * with X+ = X - t w^T and Y+ = Y - yhat q^T (yhat = T b, the inner-regression prediction),
  *   S+ = S - ya w^T - q v^T,   ya = Y^T t (M, taken before Y is deflated),  v = X+^T yhat (P, from

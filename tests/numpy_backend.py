@@ -97,6 +97,26 @@ class NumpyBackend:
         self.score(S, A, B, wA, wB, None, q_new)
         self.q_update(q_new, None, True, G, q_cur, du2)
 
+    def xcov_blocks_plan(self, blocks, M, q_cur, tq, q_new, G, status):
+        if M > 64 or any(b["order"] not in (2, 3) for b in blocks):
+            return None
+        Tq = tq.view(len(blocks), M)
+
+        def enqueue(n_squarings, first):
+            for i, b in enumerate(blocks):
+                if first:
+                    self.mode0_contract(b["S"], q_cur, False, out=b["Z"])
+                    if b["colcnt"] is not None:
+                        self.colscale(b["Z"], b["colcnt"], b["n_samples"])
+                if b["order"] == 3:
+                    self.rank1(b["Z"], b["A"], b["B"], b["wA"], b["wB"], info=status[1 + 2 * i: 3 + 2 * i], n_squarings=n_squarings[i])
+                else:
+                    b["wB"].copy_(b["Z"] / torch.linalg.norm(b["Z"]))
+                self.score(b["S2"] if b["S2"] is not None else b["S"], b["A"], b["B"], b["wA"], b["wB"], None, Tq[i])
+            q_new.copy_(Tq.mean(dim=0) if len(blocks) > 1 else Tq[0])
+            self.q_update(q_new, None, True, G, q_cur, status[0:1])
+        return enqueue
+
     def status_snapshot(self, status, slot):
         return status.clone().numpy()
 

@@ -364,6 +364,48 @@ def test_xcov_pipelined_inner_loop_is_bit_identical_to_the_waiting_loop(backend,
         np.testing.assert_allclose(pipe.X_factors[0], ref.T, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("case", ["coupled", "coupled_nan", "nan", "matrix", "coupled3"])
+def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(case, monkeypatch):
+    """The pipelined inner loop through the several-blocks entry (backend.xcov_blocks_plan: coupled blocks, blocks with missing
+    values, matrix blocks): same iteration counts and factors as the loop that waits after every iteration, and as the oracle."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    rng = np.random.default_rng(21)
+    x, y, cp = O.import_synthetic((50, 8, 6), 3, 3, error=0.2, seed=5)
+    xm = cp.factors[0] @ rng.normal(size=(11, 3)).T + 0.2 * rng.normal(size=(50, 11))
+    if case in ("coupled_nan", "nan"):
+        x = x.copy()
+        x[rng.random(x.shape) < 0.15] = np.nan
+    blocks = {"coupled": [x, xm], "coupled_nan": [x, xm], "nan": [x], "matrix": [xm],
+              "coupled3": [xm, x, rng.normal(size=(50, 4, 5))]}[case]
+    coupled = len(blocks) > 1
+    used = {"plans": 0}
+    orig = NumpyBackend.xcov_blocks_plan
+
+    def counted(self, *a, **k):
+        used["plans"] += 1
+        return orig(self, *a, **k)
+    monkeypatch.setattr(NumpyBackend, "xcov_blocks_plan", counted)
+
+    def fit(pipeline):
+        monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
+        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov")
+        m.fit(blocks if coupled else blocks[0], y)
+        return m
+
+    wait = fit(False)
+    assert used["plans"] == 0
+    pipe = fit(True)
+    assert used["plans"] > 0
+    assert pipe.n_iter_ == wait.n_iter_
+    f1 = ([pipe.factor_T] + [f for fs in pipe.Xs_factors for f in fs[1:]]) if coupled else pipe.X_factors
+    f2 = ([wait.factor_T] + [f for fs in wait.Xs_factors for f in fs[1:]]) if coupled else wait.X_factors
+    for f, g in zip(f1 + list(pipe.Y_factors), f2 + list(wait.Y_factors)):
+        np.testing.assert_allclose(f, g, rtol=1e-12, atol=1e-13)
+    ref = O.fit_ctpls(blocks, y, 3) if coupled else O.fit_tpls(blocks[0], y, 3)
+    assert pipe.n_iter_ == ref.n_iter
+    np.testing.assert_allclose(f1[0], ref.T, rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("coupled", [False, True])
 def test_xcov_masked_blocks_build_both_cross_covariances_in_one_pass(coupled, monkeypatch):
     """A block with missing values needs S = X0^T Y (contraction) and S2 = X0^T (Y * rowscale) (the masked score's P / n_obs(i)

@@ -603,3 +603,37 @@ def test_xcov_pipelined_inner_loop_is_bit_identical_to_the_waiting_loop(api, mon
             assert np.array_equal(f, g)
         assert np.array_equal(pipe.coef_, wait.coef_) and np.array_equal(pipe.R2X, wait.R2X) and np.array_equal(pipe.R2Y, wait.R2Y)
     assert pipe.n_iter_ == [3] * 5 or max(pipe.n_iter_) <= 3
+
+
+@pytest.mark.parametrize("case", ["coupled", "coupled_nan", "nan", "matrix"])
+def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(api, monkeypatch, case):
+    """Coupled blocks, blocks with missing values and matrix blocks run the pipelined inner loop through ONE host call per iteration
+    (cmtfpls_xcov_iterate_blocks_f64): same iteration counts and factors (to rounding: the q update is one kernel there, two in the
+    waiting loop) as the loop that waits after every iteration; equals the oracle."""
+    from cmtf_pls_amd.backend import HipBackend
+    from cmtf_pls_amd.engine import NipalsEngine
+    rng = np.random.default_rng(33)
+    x, y, cp = O.import_synthetic((300, 32, 64), 6, 4, error=0.2, seed=31)
+    xm = cp.factors[0] @ rng.normal(size=(96, 4)).T + 0.2 * rng.normal(size=(300, 96))
+    if case in ("coupled_nan", "nan"):
+        x[rng.random(x.shape) < 0.2] = np.nan
+    blocks = {"coupled": [x, xm], "coupled_nan": [x, xm], "nan": [x], "matrix": [xm]}[case]
+    blocks, y = [_f32(b) for b in blocks], _f32(y)
+    coupled = len(blocks) > 1
+    plans = _count_calls(monkeypatch, ["xcov_blocks_plan"])
+    fits = []
+    for pipeline in (False, True):
+        monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
+        m = (api.ctPLS if coupled else api.tPLS)(4, dtype="float32", algorithm="xcov")
+        m.fit(blocks if coupled else blocks[0], y)
+        fits.append(m)
+        assert (plans["xcov_blocks_plan"] > 0) == pipeline
+    wait, pipe = fits
+    assert pipe.n_iter_ == wait.n_iter_
+    f1 = ([pipe.factor_T] + [f for fs in pipe.Xs_factors for f in fs[1:]]) if coupled else pipe.X_factors
+    f2 = ([wait.factor_T] + [f for fs in wait.Xs_factors for f in fs[1:]]) if coupled else wait.X_factors
+    for f, g in zip(f1 + list(pipe.Y_factors), f2 + list(wait.Y_factors)):
+        assert _normwise(f, g) <= 1e-11
+    ref = O.fit_ctpls(blocks, y, 4) if coupled else O.fit_tpls(blocks[0], y, 4)
+    assert pipe.n_iter_ == ref.n_iter
+    assert _normwise(f1[0], ref.T) <= 1e-5
