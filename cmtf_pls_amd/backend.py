@@ -160,6 +160,20 @@ class HipBackend:
         _lib.check(fn(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
         return S
 
+    def xcov_ssq(self, X2: torch.Tensor, Y: torch.Tensor, mean: torch.Tensor, out: torch.Tensor):
+        """S = Y^T X_(0) AND sum (X - mean)^2 from one read of an uncentred, NaN-free X (cmtfpls_xcov_ssq_*); returns
+        (S, ssq as a one-element device tensor), or None when M > 64."""
+        I, P = X2.shape
+        M = Y.shape[1]
+        if M > 64:
+            return None
+        ws = self._workspace("contract", self.lib.cmtfpls_xcov_ssq_workspace_bytes(I, P, M))
+        ssq = self.empty(1)
+        assert mean.is_contiguous() and mean.numel() == P and mean.dtype == torch.float64
+        _lib.check(self._fn("xcov_ssq", X2)(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(out), _ptr(mean), _ptr(ssq), _ptr(ws), ws.numel(),
+                                            self._stream()), "xcov_ssq")
+        return out, ssq
+
     def status_snapshot(self, status: torch.Tensor, slot: int):
         """Enqueue a copy of a few status words to pinned host memory behind the work issued so far (cmtfpls_status_to_host);
         returns a token for status_wait.  (slot: the caller keeps at most one snapshot per slot in flight.)"""

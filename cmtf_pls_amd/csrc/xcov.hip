@@ -43,14 +43,22 @@ XcovPlan plan_xcov(int64_t I, int64_t P) {
 
 // FAST: every tile is interior (P % 256 == 0, M % 16 == 0, every row block a multiple of 32 rows):
 // no clamps and no selects, so the only VALU work per MFMA is the f32 -> f64 conversion.
-template <typename T, bool MASKED, bool VEC, int MT, bool FAST>
+// SSQ (round 3): the same read of X also gives sum (x - mean[c])^2 -- |X - X_mean|^2, the denominator of R2X (tpls.py:115-117),
+// for a fit that runs on the caller's UNCENTRED tensor (engine.FitRun.raw): the f64 value of every element is formed for the
+// MFMA anyway, so it costs a subtraction and an fma per element and saves the separate pass (cmtfpls_recon_r2_* against a zero
+// reconstruction).  One partial per wavefront, summed in index order by sum_kernel.
+template <typename T, bool MASKED, bool VEC, int MT, bool FAST, bool SSQ = false>
 __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int64_t I, int64_t P,
                                                   const double* __restrict__ Y, int ldy, int M,
-                                                  double* __restrict__ part, int rows_per_block) {
+                                                  double* __restrict__ part, int rows_per_block,
+                                                  const double* __restrict__ mean = nullptr, double* __restrict__ ssq_part = nullptr) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kq = lane >> 4, nn = lane & 15;
   const int64_t cb = ((int64_t)blockIdx.x * 4 + wv) * 64;
-  if (cb >= P) return;                                   // whole wavefront past the last column
+  if (cb >= P) {                                         // whole wavefront past the last column
+    if (SSQ && lane == 0) ssq_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = 0.0;
+    return;
+  }
   const int64_t c = cb + 4 * nn;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
@@ -75,6 +83,11 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
   int ycol[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) ycol[mt] = mok[mt] ? mt * 16 + nn : M - 1;
+  double mu[SSQ ? 4 : 1], ssq = 0.0;
+  if constexpr (SSQ) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mu[e] = mean[(c + e < P) ? c + e : P - 1];
+  }
 
   auto load_stage = [&](XV (&x)[UN], double (&a)[UN][MT], int64_t r) {
 #pragma unroll
@@ -100,6 +113,10 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
         T xv = x[s].e[e];
         if (MASKED) xv = (xv == xv) ? xv : (T)0;
         const double b = (FAST || (rok && c + e < P)) ? (double)xv : 0.0;
+        if constexpr (SSQ) {
+          const double dv = (FAST || (rok && c + e < P)) ? b - mu[e] : 0.0;
+          ssq = fma(dv, dv, ssq);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           acc[mt][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((FAST || (rok && mok[mt])) ? a[s][mt] : 0.0, b, acc[mt][e], 0, 0, 0);
@@ -116,6 +133,10 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
     // FAST has no clamp: the look-ahead of the last trip must stay inside this block's rows
     load_stage(xa, aa, (FAST && r + 8 * UN >= r1) ? r : r + 8 * UN);
     mma_stage(xb, ab, r + 4 * UN);
+  }
+  if constexpr (SSQ) {
+    ssq = wave_sum(ssq);
+    if (lane == 0) ssq_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = ssq;
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -145,13 +166,17 @@ __global__ __launch_bounds__(256) void quadform_kernel(const double* __restrict_
   if (threadIdx.x == 0) out[0] = s;
 }
 
+static size_t xcov_ssq_extra(const XcovPlan& p) { return ((size_t)p.row_blocks * p.col_tiles * 4 * sizeof(double) + 255) / 256 * 256; }
+
 template <typename T>
 static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
-                    void* ws, size_t ws_bytes, hipStream_t st) {
+                    void* ws, size_t ws_bytes, hipStream_t st, const double* mean = nullptr, double* ssq_out = nullptr) {
   if (!X || !Y || !S || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov: bad argument"); return CMTFPLS_EINVAL; }
   if (M > 64) { set_error("xcov: more than 64 responses; use the direct algorithm"); return CMTFPLS_EUNSUPPORTED; }
   const XcovPlan p = plan_xcov(I, P);
-  const size_t need = (size_t)p.row_blocks * M * P * sizeof(double);
+  const bool with_ssq = ssq_out != nullptr;
+  if (with_ssq && (masked || !mean)) { set_error("xcov_ssq: needs the column means and a block without missing values"); return CMTFPLS_EINVAL; }
+  const size_t need = (size_t)p.row_blocks * M * P * sizeof(double) + (with_ssq ? xcov_ssq_extra(p) : 0);
   if (!ws || ws_bytes < need) { set_error("xcov: workspace too small"); return CMTFPLS_EWORKSPACE; }
   const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) == 0);
   const int mt = (M + 15) / 16;                          // 1, 2, 3 -> 4, 4
@@ -159,14 +184,22 @@ static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, 
   const dim3 grid(p.col_tiles, p.row_blocks), block(256);
   const bool fast = vec && (P % 256 == 0) && (M % 16 == 0) && (M / 16 != 3) && (I % p.rows_per_block == 0) &&
                     (p.rows_per_block % (8 * 4) == 0);
-#define XL(MSK, VC, MTT, FS) hipLaunchKernelGGL((xcov_kernel<T, MSK, VC, MTT, FS>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block)
+  double* ssq_part = with_ssq ? reinterpret_cast<double*>(static_cast<char*>(ws) + (size_t)p.row_blocks * M * P * sizeof(double)) : nullptr;
+#define XL(MSK, VC, MTT, FS) hipLaunchKernelGGL((xcov_kernel<T, MSK, VC, MTT, FS>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block, (const double*)nullptr, (double*)nullptr)
+#define XS(VC, MTT, FS) hipLaunchKernelGGL((xcov_kernel<T, false, VC, MTT, FS, true>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block, mean, ssq_part)
 #define XM(MSK, VC, FS) do { if (mt == 1) XL(MSK, VC, 1, FS); else if (mt == 2) XL(MSK, VC, 2, FS); else XL(MSK, VC, 4, FS); } while (0)
-  if (masked) { if (fast) XM(true, true, true); else if (vec) XM(true, true, false); else XM(true, false, false); }
-  else        { if (fast) XM(false, true, true); else if (vec) XM(false, true, false); else XM(false, false, false); }
+#define XQ(VC, FS) do { if (mt == 1) XS(VC, 1, FS); else if (mt == 2) XS(VC, 2, FS); else XS(VC, 4, FS); } while (0)
+  if (with_ssq)    { if (fast) XQ(true, true); else if (vec) XQ(true, false); else XQ(false, false); }
+  else if (masked) { if (fast) XM(true, true, true); else if (vec) XM(true, true, false); else XM(true, false, false); }
+  else             { if (fast) XM(false, true, true); else if (vec) XM(false, true, false); else XM(false, false, false); }
+#undef XQ
 #undef XM
+#undef XS
 #undef XL
   launch_reduce_rows(part, p.row_blocks, (int64_t)M * P, S, st);
-  return check_launch("xcov");
+  int rc = check_launch("xcov");
+  if (rc == CMTFPLS_OK && with_ssq) rc = cmtfpls_sum_f64(ssq_part, (int64_t)p.row_blocks * p.col_tiles * 4, ssq_out, st);
+  return rc;
 }
 
 }  // namespace cmtfpls
@@ -187,6 +220,21 @@ int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int 
 int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
                      void* ws, size_t ws_bytes, void* stream) {
   return run_xcov<double>(X, I, P, Y, ldy, M, S, masked, ws, ws_bytes, (hipStream_t)stream);
+}
+size_t cmtfpls_xcov_ssq_workspace_bytes(int64_t I, int64_t P, int M) {
+  if (I <= 0 || P <= 0 || M <= 0) return 0;
+  const XcovPlan p = plan_xcov(I, P);
+  return (size_t)p.row_blocks * M * P * sizeof(double) + xcov_ssq_extra(p);
+}
+int cmtfpls_xcov_ssq_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, const double* mean,
+                         double* ssq, void* ws, size_t ws_bytes, void* stream) {
+  if (!mean || !ssq) { set_error("xcov_ssq: bad argument"); return CMTFPLS_EINVAL; }
+  return run_xcov<float>(X, I, P, Y, ldy, M, S, 0, ws, ws_bytes, (hipStream_t)stream, mean, ssq);
+}
+int cmtfpls_xcov_ssq_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, const double* mean,
+                         double* ssq, void* ws, size_t ws_bytes, void* stream) {
+  if (!mean || !ssq) { set_error("xcov_ssq: bad argument"); return CMTFPLS_EINVAL; }
+  return run_xcov<double>(X, I, P, Y, ldy, M, S, 0, ws, ws_bytes, (hipStream_t)stream, mean, ssq);
 }
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream) {
   if (!G || !q || !q_old || !out || M <= 0) { set_error("quadform: bad argument"); return CMTFPLS_EINVAL; }

@@ -141,6 +141,9 @@ class NipalsEngine:
     # blocks WITH missing values, 2 M <= 64: S = X0^T Y and S2 = X0^T (Y * rowscale) from one matrix-core pass with the I x 2M
     # right-hand side [Y, Y * rowscale] instead of two passes; False builds them one after the other (tests compare the two)
     xcov_pair_build = True
+    # a fit on the uncentred tensor (xcov_raw): |X - X_mean|^2 from the read that builds S for the first component instead of a
+    # read of its own (backend.xcov_ssq); False keeps the separate pass (tests compare the two)
+    xcov_ssq_with_s = True
     # the inner loop on S (one NaN-free order-3 block): iteration it + 1 is ENQUEUED before the host has seen iteration it's
     # convergence norm, into a second set of buffers -- the GPU no longer idles through the status copy, the host's wake-up and
     # the next launches (FitRun._inner_loop_xcov_pipelined); False waits after every iteration (tests compare the two bit for bit)
@@ -495,8 +498,12 @@ class FitRun:
                 if not owned[b]:
                     Xs[b] = Xs[b].clone()                        # the fit centres and deflates in place: never the caller's tensor
         self.blocks = [eng._prepare_block(X, self.n_total, defer_centring=want_raw) for X in Xs]
+        # |X - X_mean|^2 of an uncentred block: from the read that builds S for the first component (backend.xcov_ssq, M <= 64),
+        # else from a read of its own (_ssq_uncentred)
+        self._ssq_with_s = (want_raw and M <= 64 and hasattr(be, "xcov_ssq") and bool(getattr(eng, "xcov_ssq_with_s", True)))
+        self._ssq0_dev = {}
         self.raw = (want_raw and not any(blk.has_miss for blk in self.blocks)
-                    and all(eng._ssq_uncentred(blk, X) for blk, X in zip(self.blocks, Xs)))
+                    and (self._ssq_with_s or all(eng._ssq_uncentred(blk, X) for blk, X in zip(self.blocks, Xs))))
         if want_raw and not self.raw:                            # missing values (or no read-only norm): the deflating form after all
             for b, blk in enumerate(self.blocks):
                 if not owned[b]:
@@ -650,7 +657,11 @@ class FitRun:
                 be.xcov(self.X2[b], self.Yw, True, out=self.S12[b], mixed=self.mixed)
                 comm.allreduce(self.S12[b])
                 continue
-            be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b], mixed=self.mixed)
+            if self.raw and self._ssq_with_s and b not in self._ssq0_dev:
+                _, ssq = be.xcov_ssq(self.X2[b], self.Y, blk.mean, out=self.S[b])   # S and |X - X_mean|^2 from one read
+                self._ssq0_dev[b] = comm.allreduce(ssq)                       # (read back in result(), with everything else)
+            else:
+                be.xcov(self.X2[b], self.Y, blk.has_miss, out=self.S[b], mixed=self.mixed)
             comm.allreduce(self.S[b])
             if self.raw:
                 # X is uncentred: X_c^T Y = X^T Y - mean (1^T Y)^T; the centred Y sums to ~1e-13 per column, not to exactly 0
@@ -1320,6 +1331,8 @@ class FitRun:
             return self._state
         nb = len(self.blocks)
         nowrite = self.algorithm == "xcov" and getattr(self, "_nowrite", False)
+        for b, ssq in getattr(self, "_ssq0_dev", {}).items():
+            self.blocks[b].ssq0 = float(ssq.item())
         self.eng.comm.allreduce(self.ssq_log)
         parts = [self.coef_dev.reshape(-1), self.ssq_log.reshape(-1)]
         if nowrite:

@@ -120,6 +120,14 @@ int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int 
 int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
                      int masked, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream);
+/* xcov_ssq (round 3): S as cmtfpls_xcov_* (unmasked) AND ssq[0] = sum_{i,c} (X[i,c] - mean[c])^2 from the same read of an
+ * UNCENTRED X without missing values: |X - X_mean|^2, the denominator of R2X (util.py:7-20, tpls.py:115-117), for the fit that
+ * never centres, writes or copies X.  (The f64 value of every element is formed for the matrix cores anyway.) */
+size_t cmtfpls_xcov_ssq_workspace_bytes(int64_t I, int64_t P, int M);
+int cmtfpls_xcov_ssq_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, const double* mean,
+                         double* ssq, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_xcov_ssq_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, const double* mean,
+                         double* ssq, void* ws, size_t ws_bytes, void* stream);
 /* One inner iteration of the loop on S (tpls.py:80-103 re-associated) issued by a single host call:
  * Z = sum_m q_cur[m] S[m,:] (only if first != 0), rank1(Z) -> (wA, wB, info), q_new = S (wA (x) wB) normalised,
  * du2 = (q_new - q_cur)^T G (q_new - q_cur).  Same kernels as the separate entries; workspaces as

@@ -637,3 +637,45 @@ def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(api, monkeypatc
     ref = O.fit_ctpls(blocks, y, 4) if coupled else O.fit_tpls(blocks[0], y, 4)
     assert pipe.n_iter_ == ref.n_iter
     assert _normwise(f1[0], ref.T) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("I,P,M", [(4096, 16384, 16), (1000, 4096, 32), (777, 1000, 5), (130, 514, 48), (64, 256, 1)])
+def test_xcov_ssq_kernel_gives_s_and_the_centred_norm_from_one_read(be, dtype, I, P, M):
+    rng = np.random.default_rng(I + P + M)
+    x = rng.normal(size=(I, P)) * rng.uniform(0.5, 2.0, size=P) + rng.normal(size=P) * 5.0
+    if dtype == torch.float32:
+        x = _f32(x)
+    y = rng.normal(size=(I, M))
+    mean = x.mean(axis=0)
+    X = _dev(x).to(dtype)
+    S, ssq = be.xcov_ssq(X, _dev(y), _dev(mean), out=be.empty(M, P))
+    want_S = y.T @ x
+    assert np.abs(S.cpu().numpy() - want_S).max() <= 1e-12 * np.abs(want_S).max()
+    assert torch.equal(S, be.xcov(X, _dev(y), False, out=be.empty(M, P)))          # the same matrix-core pass
+    want = ((x - mean) ** 2).sum()
+    assert abs(float(ssq.item()) - want) <= 1e-12 * want
+
+
+@pytest.mark.parametrize("dtype,shape", [("float32", (400, 128, 128)), ("float64", (300, 24, 32)), ("float32", (350, 96))])
+def test_xcov_raw_fit_takes_the_norm_from_the_s_build(api, monkeypatch, dtype, shape):
+    """A fit on the uncentred tensor needs |X - X_mean|^2 for R2X: from the read that builds S (cmtfpls_xcov_ssq_*) instead of
+    a read of its own (cmtfpls_recon_r2_* against a zero reconstruction).  Same R2X."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    x, y, _ = O.import_synthetic(shape, 5, 4, error=0.1, seed=41)
+    x = x + 6.0
+    if dtype == "float32":
+        x, y = _f32(x), _f32(y)
+    calls = _count_calls(monkeypatch, ["recon_r2", "xcov_ssq", "xcov"])
+    one = api.tPLS(4, dtype=dtype, algorithm="xcov")
+    one.fit(x, y)
+    assert (calls["recon_r2"], calls["xcov_ssq"], calls["xcov"]) == (0, 1, 0)
+    monkeypatch.setattr(NipalsEngine, "xcov_ssq_with_s", False)
+    two = api.tPLS(4, dtype=dtype, algorithm="xcov")
+    two.fit(x, y)
+    assert (calls["recon_r2"], calls["xcov_ssq"], calls["xcov"]) == (1, 1, 1)
+    assert one.n_iter_ == two.n_iter_
+    assert_allclose(one.R2X, two.R2X, rtol=0, atol=1e-12)
+    assert np.array_equal(one.X_factors[0], two.X_factors[0])
+    fit = O.fit_tpls(x, y, 4)
+    assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-6 if dtype == "float32" else 1e-9)

@@ -127,3 +127,65 @@ for case in range(N // 3):
         assert e < 1e-7, ("fit_small", shape, M, R, e)
     assert np.abs(np.asarray(one.R2X) - reg.R2X).max() < 1e-10 and np.abs(np.asarray(one.R2Y) - reg.R2Y).max() < 1e-10
 print(f"one-launch small fit: {n_small} random cases ok", flush=True)
+
+# ---- score + contraction in one read (scorecontract.hip) -----------------------------------------------------------------------
+n_sc = 0
+for case in range(N):
+    dt = [torch.float32, torch.float64][int(rng.integers(2))]
+    V = 4 if dt == torch.float32 else 2
+    A = int(rng.choice([1, 2, 3, 8, 16, 50, 64, 128]))
+    B = V * int(rng.integers(1, 2048 // V + 1))
+    I = int(rng.integers(1, 600))
+    x = rng.normal(size=(I, A * B)) + 1.5
+    if dt == torch.float32:
+        x = x.astype(np.float32).astype(np.float64)
+    wA, wB = rng.normal(size=A), rng.normal(size=B)
+    use = rng.integers(2, size=3)
+    sh, sub, oth = (np.array([rng.normal()]) if use[0] else None), (rng.normal(size=I) if use[1] else None), (rng.normal(size=I) if use[2] else None)
+    alpha = float(rng.choice([1.0, 0.5, 1.0 / 3.0]))
+    t, Z = be.empty(I), be.empty(A * B)
+    out = be.score_contract(dev(x, dt), A, B, dev(wA), dev(wB), None if sh is None else dev(sh), t, Z,
+                            sub_own=None if sub is None else dev(sub), add_other=None if oth is None else dev(oth), alpha=alpha)
+    P = A * B
+    if out is None:
+        assert P > 16384 or P < 512 * V, ("score_contract declined", I, A, B, dt)
+        continue
+    n_sc += 1
+    want_t = x @ np.kron(wA, wB) - (0.0 if sh is None else sh[0]) - (0.0 if sub is None else sub)
+    want_Z = x.T @ (alpha * (want_t + (0.0 if oth is None else oth)))
+    assert np.abs(t.cpu().numpy() - want_t).max() <= 1e-11 * max(np.abs(want_t).max(), 1e-300), ("score_contract t", I, A, B, dt)
+    assert np.abs(Z.cpu().numpy() - want_Z).max() <= 1e-11 * max(np.abs(want_Z).max(), 1e-300), ("score_contract Z", I, A, B, dt)
+print(f"score_contract: {n_sc} random cases ok ({N - n_sc} declined by shape)", flush=True)
+
+# ---- the cross-covariance loop (one read per component, pipelined inner loop, paired S build) against the direct loop -------------
+n_x = 0
+for case in range(N // 3):
+    f32 = bool(rng.integers(2))
+    kind = str(rng.choice(["tensor", "coupled", "nan", "coupled_nan", "matrix"]))
+    I = int(rng.integers(40, 400))
+    A, B = int(rng.choice([8, 16, 32, 64])), int(rng.choice([32, 64, 128, 256]))
+    M, R = int(rng.integers(1, 9)), int(rng.integers(1, 6))
+    x, y, cp = O.import_synthetic((I, A, B), M, max(R, 2), error=0.3, seed=int(rng.integers(1 << 30)))
+    x = x + float(rng.choice([0.0, 5.0]))
+    xm = cp.factors[0] @ rng.normal(size=(int(rng.choice([16, 96, 512])), max(R, 2))).T + 0.3 * rng.normal(size=(I, 1))
+    if "nan" in kind:
+        x[rng.random(x.shape) < 0.2] = np.nan
+    blocks = {"tensor": [x], "nan": [x], "matrix": [xm], "coupled": [xm, x], "coupled_nan": [x, xm]}[kind]
+    if f32:
+        blocks, y = [b.astype(np.float32).astype(np.float64) for b in blocks], y.astype(np.float32).astype(np.float64)
+    dtype = "float32" if f32 else "float64"
+    coupled = len(blocks) > 1
+    arg = blocks if coupled else blocks[0]
+    d = (ctPLS if coupled else tPLS)(R, dtype=dtype)
+    d.fit(arg, y)
+    xc = (ctPLS if coupled else tPLS)(R, dtype=dtype, algorithm="xcov")
+    xc.fit(arg, y)
+    Td, Tx = (d.factor_T, xc.factor_T) if coupled else (d.X_factors[0], xc.X_factors[0])
+    if d.n_iter_ != xc.n_iter_:      # an iteration count may differ by one when |du| lands within rounding of tol
+        assert max(abs(a - b) for a, b in zip(d.n_iter_, xc.n_iter_)) <= 1, ("xcov n_iter", kind, (I, A, B), M, R, d.n_iter_, xc.n_iter_)
+        continue
+    n_x += 1
+    e = normwise(Tx, Td)
+    assert e < (5e-5 if f32 else 1e-7), ("xcov vs direct", kind, (I, A, B), M, R, dtype, e)
+    assert np.abs(np.asarray(xc.R2Y) - d.R2Y).max() < (1e-5 if f32 else 1e-9), ("xcov R2Y", kind)
+print(f"xcov (one read, pipelined, paired S build) vs direct: {n_x} random fits ok; pipeline {getattr(xc._engine, 'pipeline_stats', None) if hasattr(xc, '_engine') else ''}", flush=True)
