@@ -388,7 +388,7 @@ def test_xcov_on_the_uncentred_tensor_equals_the_centred_form(api, monkeypatch, 
 
 
 def test_xcov_fit_of_a_device_tensor_neither_writes_nor_copies_it(api):
-    """tPLS(algorithm="xcov").fit(X_device): X is read R + 3 times and that is all -- same bits afterwards, and the fit's peak
+    """tPLS(algorithm="xcov").fit(X_device): X is read R + 2 times and that is all -- same bits afterwards, and the fit's peak
     memory stays far below a second copy of X (inputs are never modified, tpls.py:74, without paying for a clone)."""
     from cmtf_pls_amd.synthetic import synthetic_shard_device
     X, Y = synthetic_shard_device((8192, 128, 128), 16, 10, error=0.1, device="cuda:0")          # 537 MB
