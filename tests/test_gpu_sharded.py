@@ -36,6 +36,44 @@ def _worker(rank, world, port, case, ret):
         from cmtf_pls_amd.backend import HipBackend
         from cmtf_pls_amd.engine import Comm, NipalsEngine
 
+        if case in ("xcov_long_rows", "xcov_coupled"):
+            # rows long enough for the one-read form of the cross-covariance loop (scorecontract.hip): its r_a = X_0^T t_a and the
+            # raw-mode corrections are summed over the ranks; coupled: the several-blocks iteration under the pipelined loop
+            from cmtf_pls_amd import ctPLS
+            x, y, cp = O.import_synthetic((512, 32, 64), 4, 3, error=0.2, seed=23)
+            x = x + 3.0
+            half = 256
+            rows = slice(rank * half, (rank + 1) * half)
+            calls = {"n": 0}
+            orig = HipBackend.score_contract
+
+            def counted(self, *a, **k):
+                out = orig(self, *a, **k)
+                calls["n"] += out is not None
+                return out
+            HipBackend.score_contract = counted
+            if case == "xcov_coupled":
+                xm = cp.factors[0] @ np.random.default_rng(4).normal(size=(40, 3)).T - 1.0
+                fit = O.fit_ctpls([xm, x], y, 3)
+                m = ctPLS(3, device="cuda:0", comm=Comm(), algorithm="xcov")
+                m.fit([xm[rows], x[rows]], y[rows])
+                T, r2 = m.factor_T, m.R2Xs[1]
+                want_r2 = fit.r2x[1]
+            else:
+                fit = O.fit_tpls(x, y, 3)
+                m = tPLS(3, device="cuda:0", comm=Comm(), algorithm="xcov")
+                m.fit(x[rows], y[rows])
+                T, r2 = m.X_factors[0], m.R2X
+                want_r2 = fit.r2x[0]
+            assert calls["n"] == 2                                   # components 0 and 1 (the last needs no down-date)
+            s = np.abs(fit.T).max()
+            assert list(m.n_iter_) == list(fit.n_iter)
+            np.testing.assert_allclose(T, fit.T[rows], rtol=1e-7, atol=1e-7 * s)
+            np.testing.assert_allclose(m.Y_factors[1], fit.Q, rtol=1e-7, atol=1e-8)
+            np.testing.assert_allclose(r2, want_r2, rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-7, atol=1e-9)
+            ret[rank] = "ok"
+            return
         x, y, _ = O.import_synthetic((512, 16, 12), 4, 3, error=0.2, seed=23)
         if case == "nan":
             x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
@@ -73,7 +111,7 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["plain", "nan", "xcov", "graphs"])
+@pytest.mark.parametrize("case", ["plain", "nan", "xcov", "graphs", "xcov_long_rows", "xcov_coupled"])
 def test_two_ranks_one_gpu(case):
     world = 2
     with mp.Manager() as mgr:
