@@ -14,8 +14,7 @@ constexpr size_t kSmallWsBytes = (size_t)kSmallBlocks * kMaxGramDim * kMaxGramDi
 // C = A^T B, per-workgroup partials: part[blk][p*b + q]
 __global__ __launch_bounds__(256) void gram_tn_kernel(const double* __restrict__ A, int lda, int a,
                                                      const double* __restrict__ B, int ldb, int b,
-                                                     int64_t I, double* __restrict__ part) {
-  constexpr int TR = 32;
+                                                     int64_t I, double* __restrict__ part, int TR) {
   extern __shared__ double lds[];
   double* As = lds;            // TR x a
   double* Bs = lds + TR * a;   // TR x b
@@ -330,8 +329,11 @@ int cmtfpls_gram_tn_f64(const double* A, int lda, int a, const double* B, int ld
     for (int b0 = 0; b0 < b; b0 += kMaxGramDim) {
       const int ac = (a - a0 < kMaxGramDim) ? a - a0 : kMaxGramDim;
       const int bc = (b - b0 < kMaxGramDim) ? b - b0 : kMaxGramDim;
-      const size_t lds = (size_t)32 * (ac + bc) * sizeof(double);
-      hipLaunchKernelGGL(gram_tn_kernel, dim3(kSmallBlocks), dim3(256), lds, st, A + a0, lda, ac, B + b0, ldb, bc, I, part);
+      // rows staged per barrier pair: as many as 32 KB of LDS hold (32 rows of a 16 x 16 Gram left the kernel waiting on its
+      // barriers: 31-39 us for 65536 rows)
+      const int tr = (ac + bc <= 32) ? 128 : (ac + bc <= 64) ? 64 : 32;
+      const size_t lds = (size_t)tr * (ac + bc) * sizeof(double);
+      hipLaunchKernelGGL(gram_tn_kernel, dim3(kSmallBlocks), dim3(256), lds, st, A + a0, lda, ac, B + b0, ldb, bc, I, part, tr);
       hipLaunchKernelGGL(reduce_block_kernel, dim3((ac * bc + 3) / 4), dim3(256), 0, st, part, kSmallBlocks, ac, bc,
                          C + (size_t)a0 * b + b0, b);
     }
