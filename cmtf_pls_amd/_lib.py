@@ -61,8 +61,8 @@ SIGNATURES = {
     "cmtfpls_xcov_ssq_f32": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_xcov_ssq_f64": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_score_contract_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "cmtfpls_score_contract_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_double, _P, _P, _P, c_size_t, _P]),
-    "cmtfpls_score_contract_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_double, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_score_contract_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_double, _P, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_score_contract_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_double, _P, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_kr_axpy_f64": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),
     "cmtfpls_xcov_f32_mixed": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_mttkrp_f32_mixed": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, _P, c_int, _P]),
@@ -90,6 +90,7 @@ SIGNATURES = {
     "cmtfpls_normal_solve_workspace_bytes": (c_size_t, [c_int]),
     "cmtfpls_normal_solve_ws_f64": (c_int, [_P, _P, c_int, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_unit_upper_solve_rows_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "cmtfpls_kr_gram_row_f64": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     "cmtfpls_kr_gram_f64": (c_int, [_P, c_int, c_int, _P, c_int, c_double, _P]),
     "cmtfpls_khatri_rao_f64": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "cmtfpls_predict_rows_f64": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P, _P, c_int, _P]),

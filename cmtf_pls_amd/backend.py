@@ -302,9 +302,10 @@ class HipBackend:
         _lib.check(self._fn("score", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), self._stream()), "score")
         return out
 
-    def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha: float = 1.0) -> Optional[torch.Tensor]:
-        """t = X w - shift - sub_own and Z = X^T (alpha (t + add_other)) in one read of X (cmtfpls_score_contract_*); None when the
-        row does not fit the registers of one workgroup (the caller then makes the two passes)."""
+    def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha: float = 1.0,
+                       csum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """t = X w - shift - sub_own and Z = X^T c, c = alpha (t + add_other), in one read of X (cmtfpls_score_contract_*); csum[0] =
+        sum(c) when given; None when the row does not fit the registers of one workgroup (the caller then makes the two passes)."""
         I, P = X2.shape
         if not X2.is_contiguous() or P != A * B:
             return None
@@ -313,7 +314,7 @@ class HipBackend:
         nbytes = self.lib.cmtfpls_score_contract_workspace_bytes(I, P)
         ws = self._workspace("score_contract", max(nbytes, 256))
         rc = self._fn("score_contract", X2)(_ptr(X2), I, A, B, _ptr(wA), _ptr(wB), _ptr(shift), _ptr(sub_own), _ptr(add_other), float(alpha),
-                                            _ptr(t), _ptr(Z), _ptr(ws), ws.numel(), self._stream())
+                                            _ptr(t), _ptr(Z), _ptr(csum), _ptr(ws), ws.numel(), self._stream())
         if rc == 4:
             return None
         _lib.check(rc, "score_contract")
@@ -420,6 +421,12 @@ class HipBackend:
         _lib.check(self.lib.cmtfpls_unit_upper_solve_rows_f64(_ptr(M), I, M.stride(0), R, _ptr(U), _ptr(shift), _ptr(nan_flag),
                                                               self._stream()), "unit_upper_solve_rows")
         return M
+
+    def kr_gram_row(self, L: torch.Tensor, a: int, g: torch.Tensor, first: bool) -> torch.Tensor:
+        """g[:a] (*)= L[:, :a]^T L[:, a]: row a of the loadings' Gram matrix (cmtfpls_kr_gram_row_f64)."""
+        assert L.is_contiguous() and g.is_contiguous() and g.numel() >= a
+        _lib.check(self.lib.cmtfpls_kr_gram_row_f64(_ptr(L), L.shape[0], L.shape[1], int(a), _ptr(g), int(first), self._stream()), "kr_gram_row")
+        return g
 
     def kr_gram(self, L: torch.Tensor, G: torch.Tensor, first: bool) -> torch.Tensor:
         """G = L^T L (first) or G .*= L^T L: Gram of a Khatri-Rao product, one mode at a time."""

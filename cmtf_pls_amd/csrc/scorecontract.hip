@@ -15,7 +15,8 @@
 // in every row -- their loading products and NV * V f64 accumulators of Z in registers; the row's dot product is a block sum
 // (one barrier per row), the next row's loads are in flight meanwhile (always issued: a row index clamped to the last row
 // instead of a branch, which would make the compiler wait for every load).  One partial row of Z per workgroup, added in index
-// order by reduce_rows_kernel.  shift (device, nullable): X is uncentred, t = X w - mean^T w.
+// order by reduce_rows_kernel.  shift (device, nullable): X is uncentred, t = X w - mean^T w.  csum (nullable): sum_i c[i], what the
+// rank-one correction X_c^T c = X^T c - (1^T c) mean of an uncentred X needs (a 65536-element sum_kernel launch otherwise).
 // Shapes: B % V == 0, rows of at most 1024 * V * 4 (f32) / 1024 * V * 8 (f64) elements = 16384; no missing values.
 #include "common.hpp"
 
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
                                                                   const double* __restrict__ wA, const double* __restrict__ wB,
                                                                   const double* __restrict__ shift, const double* __restrict__ sub_own,
                                                                   const double* __restrict__ add_other, double alpha,
-                                                                  double* __restrict__ t, double* __restrict__ part) {
+                                                                  double* __restrict__ t, double* __restrict__ part,
+                                                                  double* __restrict__ csum_part) {
   __shared__ double red[2][16];
   __shared__ double wls[WL ? kScLdsA : 1];
   constexpr int V = VecOf<T>::N;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
   int64_t r = blockIdx.x;
   VT bufA[NV], bufB[NV];                                     // fixed roles, never copied (a copy would wait for the loads)
   int parity = 0;
+  double csum = 0.0;
   auto load = [&](VT (&buf)[NV], int64_t row) {
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
     if (threadIdx.x == 0) t[row] = ti;
     if (add_other) ti += add_other[row];
     ti *= alpha;
+    csum += ti;                                                // (every lane carries the same running sum of the weights)
     if constexpr (sizeof(T) == 4) {                          // convert again rather than keep 16 f64 copies alive across the barrier
 #pragma unroll
       for (int n = 0; n < NV; ++n)
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
     use(bufB, r1);
     r = r2;
   }
+  if (csum_part && threadIdx.x == 0) csum_part[blockIdx.x] = csum;
   double* __restrict__ prow = part + (int64_t)blockIdx.x * P + c0;
 #pragma unroll
   for (int n = 0; n < NV; ++n)
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
 
 template <typename T>
 static int run_score_contract(const T* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                              const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
-                              size_t ws_bytes, hipStream_t st) {
+                              const double* sub_own, const double* add_other, double alpha, double* t, double* Z, double* csum,
+                              void* ws, size_t ws_bytes, hipStream_t st) {
   if (!X || !wA || !wB || !t || !Z || I <= 0 || A <= 0 || B <= 0) { set_error("score_contract: bad argument"); return CMTFPLS_EINVAL; }
   constexpr int V = 16 / (int)sizeof(T);
   const int64_t P = (int64_t)A * B;
@@ -167,24 +172,26 @@ static int run_score_contract(const T* X, int64_t I, int A, int B, const double*
     return CMTFPLS_EUNSUPPORTED;
   }
   const int grid = (int)(I < kScGrid ? I : kScGrid);
-  if (!ws || ws_bytes < (size_t)grid * P * sizeof(double)) { set_error("score_contract: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  if (!ws || ws_bytes < (size_t)grid * (P + 1) * sizeof(double)) { set_error("score_contract: workspace too small"); return CMTFPLS_EWORKSPACE; }
   double* part = static_cast<double*>(ws);
+  double* csum_part = csum ? part + (size_t)grid * P : nullptr;
   const bool kc = (stride % B) == 0;
 #define SCL(NVV)                                                                                                                  \
   do {                                                                                                                            \
-    if (kc) hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part); \
-    else hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, false>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part); \
+    if (kc) hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part, csum_part); \
+    else hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, false>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part, csum_part); \
   } while (0)
   if (nv <= 1) SCL(1);
   else if (nv <= 2) SCL(2);
   else if (nv <= 4) SCL(4);
   else if constexpr (kMaxNV >= 8) {
     if (kc && P == 8 * stride && A <= kScLdsA)
-      hipLaunchKernelGGL((score_contract_rows_kernel<T, 8, true, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part);
+      hipLaunchKernelGGL((score_contract_rows_kernel<T, 8, true, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part, csum_part);
     else SCL(8);
   }
 #undef SCL
   launch_reduce_rows(part, grid, P, Z, st);
+  if (csum) launch_reduce_rows(csum_part, grid, 1, csum, st);
   return check_launch("score_contract");
 }
 
@@ -195,16 +202,16 @@ using namespace cmtfpls;
 extern "C" {
 size_t cmtfpls_score_contract_workspace_bytes(int64_t I, int64_t P) {
   if (I <= 0 || P <= 0) return 0;
-  return (size_t)(I < kScGrid ? I : kScGrid) * (size_t)P * sizeof(double);
+  return (size_t)(I < kScGrid ? I : kScGrid) * (size_t)(P + 1) * sizeof(double);
 }
 int cmtfpls_score_contract_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
-                               size_t ws_bytes, void* stream) {
-  return run_score_contract<float>(X, I, A, B, wA, wB, shift, sub_own, add_other, alpha, t, Z, ws, ws_bytes, (hipStream_t)stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, double* csum,
+                               void* ws, size_t ws_bytes, void* stream) {
+  return run_score_contract<float>(X, I, A, B, wA, wB, shift, sub_own, add_other, alpha, t, Z, csum, ws, ws_bytes, (hipStream_t)stream);
 }
 int cmtfpls_score_contract_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
-                               size_t ws_bytes, void* stream) {
-  return run_score_contract<double>(X, I, A, B, wA, wB, shift, sub_own, add_other, alpha, t, Z, ws, ws_bytes, (hipStream_t)stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, double* csum,
+                               void* ws, size_t ws_bytes, void* stream) {
+  return run_score_contract<double>(X, I, A, B, wA, wB, shift, sub_own, add_other, alpha, t, Z, csum, ws, ws_bytes, (hipStream_t)stream);
 }
 }

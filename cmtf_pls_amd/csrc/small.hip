@@ -27,8 +27,16 @@ __global__ __launch_bounds__(256) void gram_tn_kernel(const double* __restrict__
   for (int s = 0; s < 16; ++s) acc[s] = 0.0;
   for (int64_t rb = r0; rb < r1; rb += TR) {
     const int nr = (int)((r1 - rb < TR) ? r1 - rb : TR);
-    for (int idx = threadIdx.x; idx < nr * a; idx += 256) As[idx] = A[(rb + idx / a) * lda + idx % a];
-    for (int idx = threadIdx.x; idx < nr * b; idx += 256) Bs[idx] = B[(rb + idx / b) * ldb + idx % b];
+    if (lda == a) {                                          // contiguous rows (Y, a score vector): no index arithmetic
+      for (int idx = threadIdx.x; idx < nr * a; idx += 256) As[idx] = A[rb * a + idx];
+    } else {
+      for (int idx = threadIdx.x; idx < nr * a; idx += 256) As[idx] = A[(rb + idx / a) * lda + idx % a];
+    }
+    if (ldb == b) {
+      for (int idx = threadIdx.x; idx < nr * b; idx += 256) Bs[idx] = B[rb * b + idx];
+    } else {
+      for (int idx = threadIdx.x; idx < nr * b; idx += 256) Bs[idx] = B[(rb + idx / b) * ldb + idx % b];
+    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 16; ++s) {

@@ -172,6 +172,28 @@ __global__ __launch_bounds__(256) void kr_gram_kernel(const double* __restrict__
   }
 }
 
+// g[j] = (first ? 1 : g[j]) * sum_i L[i][j] L[i][a],  j < a: ROW a of the Gram matrix above, all the never-writing cross-covariance
+// loop needs per component (w_j^T w_a, j < a) -- a launches' worth of latency instead of the R x R matrix by one lane per entry
+// walking n rows (22 us at 128 x 10).  One workgroup; 16 rows of loads in flight per lane.
+__global__ __launch_bounds__(256) void kr_gram_row_kernel(const double* __restrict__ L, int n, int R, int a, double* __restrict__ g, int first) {
+  for (int j = threadIdx.x; j < a; j += 256) {
+    double acc = 0.0;
+    int i = 0;
+    for (; i + 16 <= n; i += 16) {
+      double x[16], y[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        x[u] = L[(int64_t)(i + u) * R + j];
+        y[u] = L[(int64_t)(i + u) * R + a];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fma(x[u], y[u], acc);
+    }
+    for (; i < n; ++i) acc = fma(L[(int64_t)i * R + j], L[(int64_t)i * R + a], acc);
+    g[j] = (first ? 1.0 : g[j]) * acc;
+  }
+}
+
 // out[(j * nb + k) * R + r] = Am[j * R + r] * Bm[k * R + r]
 __global__ __launch_bounds__(256) void khatri_rao_kernel(const double* __restrict__ Am, int na, const double* __restrict__ Bm, int nb,
                                                         int R, double* __restrict__ out) {
@@ -240,6 +262,13 @@ int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, dou
   if (!L || !G || n <= 0 || R <= 0) { set_error("kr_gram: bad argument"); return CMTFPLS_EINVAL; }
   hipLaunchKernelGGL(kr_gram_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, L, n, R, G, first, scale);
   return check_launch("kr_gram");
+}
+
+int cmtfpls_kr_gram_row_f64(const double* L, int n, int R, int a, double* g, int first, void* stream) {
+  if (!L || !g || n <= 0 || R <= 0 || a < 0 || a >= R) { set_error("kr_gram_row: bad argument"); return CMTFPLS_EINVAL; }
+  if (a == 0) return CMTFPLS_OK;
+  hipLaunchKernelGGL(kr_gram_row_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, L, n, R, a, g, first);
+  return check_launch("kr_gram_row");
 }
 
 int cmtfpls_predict_rows_f64(const double* S, int64_t I, int lds_, int R, const double* Bm, int M, const double* mean, double* out, int ldo,

@@ -633,6 +633,7 @@ class FitRun:
                         self.ps = be.empty(P0)
                         self.Rm = be.zeros(P0, R)                                # column j: X_0^T t_j
                         self.corr = be.empty(I)
+                        self.csum = be.empty(1)
             assert self._nowrite or not self.raw, "an uncentred X needs the form of the loop that never writes it"
 
     def start_component(self, a: int) -> None:
@@ -1259,10 +1260,14 @@ class FitRun:
             if self.raw:                                                         # uncentred X: X_c w = X w - (mean^T w) 1
                 mw = be.score(blk.mean.view(1, -1), blk.A, blk.B, self.wA[b], self.wB[b], None, be.empty(1))
             g = None
-            if a > 0:
-                for m, L in enumerate(blk.loadings):                             # Gram of a Khatri-Rao product =
-                    be.kr_gram(L, self.Gw, first=(m == 0))                       # Hadamard product of the mode Grams
-                g = self.Gw.view(R, R)[a, :a]                                    # w_j^T w_a, j < a (row a of the symmetric Gram)
+            if a > 0 and hasattr(be, "kr_gram_row"):
+                for m, L in enumerate(blk.loadings):                             # Gram of a Khatri-Rao product = Hadamard product
+                    be.kr_gram_row(L, a, self.Gw, first=(m == 0))                # of the mode Grams; only its row a is needed:
+                g = self.Gw[:a]                                                  # w_j^T w_a, j < a
+            elif a > 0:
+                for m, L in enumerate(blk.loadings):
+                    be.kr_gram(L, self.Gw, first=(m == 0))
+                g = self.Gw.view(R, R)[a, :a]                                    # (row a of the symmetric Gram)
             if b == fused_b:
                 # t_b = X_0 w_a - T[:, :a] g and r_a = X_0^T t_a (t_a: the average over the blocks, cmtf.py:120) from the same read
                 # of X (this rank's rows; r_a summed over ranks below)
@@ -1275,7 +1280,8 @@ class FitRun:
                 elif nb > 2:
                     others = self.Ts[[x for x in range(nb) if x != b]].sum(dim=0)
                 one_read = be.score_contract(self.X2[b], blk.A, blk.B, self.wA[b], self.wB[b], mw, self.Ts[b], self.ps,
-                                             sub_own=corr, add_other=others, alpha=1.0 / nb) is not None
+                                             sub_own=corr, add_other=others, alpha=1.0 / nb,
+                                             csum=self.csum if self.raw else None) is not None
                 if one_read:
                     continue
                 self._one_read = False                                           # shape outside that kernel: two passes from here on
@@ -1289,8 +1295,8 @@ class FitRun:
             be.scores_mean(self.Ts, self.t)                                      # cmtf.py:120
         if one_read:
             comm.allreduce(self.ps)
-            if self.raw:                                                         # X_c^T t = X^T t - (1^T t) mean
-                be.axpy_scalar(self.ps, comm.allreduce(be.total(self.t)), self.blocks[fused_b].mean)
+            if self.raw:                                                         # X_c^T t = X^T t - (1^T t) mean; 1^T t from the same pass
+                be.axpy_scalar(self.ps, comm.allreduce(self.csum), self.blocks[fused_b].mean)
             self.Rm[:, a].copy_(self.ps)
         be.rowdot(self.Y, self.q, self.u, None)                                  # u = Y q (tpls.py:102)
         be.gram_tn(self.t, self.t, out=self.dot_log[a, 0:1])

@@ -185,14 +185,15 @@ int cmtfpls_axpy_scalar_f64(double* y, int64_t n, const double* a, const double*
  * block-averaged score the deflation uses, for the block that is read last.
  * A row lives in the registers of one 1024-thread workgroup: B % (16 / sizeof) == 0, 512 * (16 / sizeof) <= A * B <= 16384, no
  * missing values; CMTFPLS_EUNSUPPORTED otherwise (use cmtfpls_score_* + cmtfpls_mode0_contract_*).
+ * csum (nullable): csum[0] = sum_i c[i] (the uncentred form's correction X_c^T c = X^T c - (1^T c) mean).
  * ws: cmtfpls_score_contract_workspace_bytes(I, A * B). */
 size_t cmtfpls_score_contract_workspace_bytes(int64_t I, int64_t P);
 int cmtfpls_score_contract_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
-                               size_t ws_bytes, void* stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, double* csum,
+                               void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_score_contract_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
-                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, void* ws,
-                               size_t ws_bytes, void* stream);
+                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, double* csum,
+                               void* ws, size_t ws_bytes, void* stream);
 /* Opt-in mixed-precision forms of xcov and mttkrp for f32-stored X: v_mfma_f32_16x16x4_f32 (half the
  * matrix cycles of the f64 form, HBM-bound instead of matrix-pipe-bound).  X is exact; the other
  * operand is rounded once to f32; f32 accumulation only inside chains of 64 rows (xcov) / 256 columns
@@ -355,6 +356,9 @@ int cmtfpls_normal_solve_ws_f64(const double* G, const double* g, int k, double*
 int cmtfpls_unit_upper_solve_rows_f64(double* M, int64_t I, int ld, int R, const double* U, const double* shift, int* nan_flag,
                                       void* stream);
 int cmtfpls_kr_gram_f64(const double* L, int n, int R, double* G, int first, double scale, void* stream);
+/* Row a of that Gram matrix only: g[j] = (first ? 1 : g[j]) * sum_i L[i][j] L[i][a] for j < a -- w_j^T w_a, what the never-writing
+ * cross-covariance loop needs per component (the score correction T[:, :a] g). */
+int cmtfpls_kr_gram_row_f64(const double* L, int n, int R, int a, double* g, int first, void* stream);
 int cmtfpls_khatri_rao_f64(const double* Am, int na, const double* Bm, int nb, int R, double* out, void* stream);
 /* predict_rows: out[i, m] = mean[m] + sum_a S[i*lds + a] * Bm[a*M + m]: `X_projection @ coef_ @ Q^T + Y_mean` (tpls.py:143,
  * cmtf.py:177) applied to the device-resident scores, Bm = coef_ Q^T (R x M, formed by the caller); mean nullable. */

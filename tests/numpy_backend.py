@@ -187,7 +187,7 @@ class NumpyBackend:
         out.copy_(torch.from_numpy(t))
         return out
 
-    def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha=1.0):
+    def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha=1.0, csum=None):
         if X2.shape[1] % 2 == 1:
             return None        # stands for "row outside the registers of one workgroup": the engine must make the two passes
         x = _np(X2).astype(np.float64)
@@ -197,6 +197,8 @@ class NumpyBackend:
         t.copy_(torch.from_numpy(s))
         c = alpha * (s + (_np(add_other) if add_other is not None else 0.0))
         Z.copy_(torch.from_numpy(x.T @ c))
+        if csum is not None:
+            csum[0] = float(np.sum(c))
         return Z
 
     def deflate(self, X2, A, B, t, wA, wB):
@@ -249,6 +251,14 @@ class NumpyBackend:
             m = m - _np(shift)[None, :]
         M.copy_(torch.from_numpy(np.ascontiguousarray(np.linalg.solve(tri.T, m.T).T)))
         return M
+
+    def kr_gram_row(self, L, a, g, first):
+        row = torch.from_numpy(_np(L)[:, :a].T @ _np(L)[:, a])
+        if first:
+            g[:a] = row
+        else:
+            g[:a] *= row
+        return g
 
     def kr_gram(self, L, G, first):
         g = torch.from_numpy(_np(L).T @ _np(L)).reshape(G.shape)

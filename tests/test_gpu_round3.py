@@ -445,9 +445,12 @@ def test_score_contract_kernel_equals_the_two_passes(be, dtype, I, A, B, shift):
     assert np.abs((Z - Z2).cpu().numpy()).max() <= 1e-12 * np.abs(want_Z).max()
     # the coupled form: own correction, the other blocks' scores, the block average
     sub, oth = rng.normal(size=I) * 10, rng.normal(size=I) * 10
-    out = be.score_contract(X, A, B, _dev(wA), _dev(wB), _dev(sh) if shift else None, t, Z, sub_own=_dev(sub), add_other=_dev(oth), alpha=0.5)
+    cs = be.empty(1)
+    out = be.score_contract(X, A, B, _dev(wA), _dev(wB), _dev(sh) if shift else None, t, Z, sub_own=_dev(sub), add_other=_dev(oth), alpha=0.5,
+                            csum=cs)
     assert out is not None
     want_c = 0.5 * (want_t - sub + oth)
+    assert abs(float(cs.item()) - want_c.sum()) <= 1e-12 * np.abs(want_c).sum()
     assert np.abs(t.cpu().numpy() - (want_t - sub)).max() <= 1e-12 * np.abs(want_t).max()
     assert np.abs(Z.cpu().numpy() - x.T @ want_c).max() <= 1e-12 * np.abs(x.T @ want_c).max()
 
