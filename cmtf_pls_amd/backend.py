@@ -160,6 +160,24 @@ class HipBackend:
         _lib.check(fn(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(S), int(masked), _ptr(ws), ws.numel(), self._stream()), "xcov")
         return S
 
+    def xcov_deflate(self, X2: torch.Tensor, A: int, B: int, Y: torch.Tensor, t: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
+                     out: torch.Tensor) -> Optional[torch.Tensor]:
+        """X -= t (x) w in place AND S = Y^T X0 of the deflated block (NaN -> 0) AND |X0|^2, one read + write of X
+        (cmtfpls_xcov_deflate_*).  Returns the norm (one-element device tensor); None when the shape is outside the kernel
+        (nothing written: deflate, then xcov)."""
+        I, P = X2.shape
+        M = Y.shape[1]
+        if M > 64 or P % 4 != 0 or P != A * B:
+            return None
+        ws = self._workspace("contract", self.lib.cmtfpls_xcov_ssq_workspace_bytes(I, P, M))
+        ssq = self.empty(1)
+        rc = self._fn("xcov_deflate", X2)(_ptr(X2), I, A, B, _ptr(Y), Y.stride(0), M, _ptr(t), _ptr(wA), _ptr(wB), _ptr(out), _ptr(ssq),
+                                          _ptr(ws), ws.numel(), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "xcov_deflate")
+        return ssq
+
     def xcov_ssq(self, X2: torch.Tensor, Y: torch.Tensor, mean: torch.Tensor, out: torch.Tensor):
         """S = Y^T X_(0) AND sum (X - mean)^2 from one read of an uncentred, NaN-free X (cmtfpls_xcov_ssq_*); returns
         (S, ssq as a one-element device tensor), or None when M > 64."""

@@ -152,6 +152,110 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
     }
 }
 
+// Deflation AND the next component's cross-covariance in one read + write of X (round 3, blocks WITH missing values, whose S
+// cannot be carried algebraically -- the masked deflation is not a rank-one update of S):
+//   X[i,c] <- (T)(X[i,c] - (t[i] wA[c / B]) wB[c % B])      tpls.py:109; NaN (missing) stays NaN; the same fma as deflate_rows_kernel
+//   S[m,c]  = sum_i Y[i,m] X0[i,c],  X0 = the deflated, ROUNDED X with NaN -> 0   (what cmtfpls_xcov_* would read afterwards)
+//   ssq     = sum X0^2                                       the numerator of R2X (tpls.py:115-117)
+// Same tiling, staging and MFMA order as xcov_kernel<T, true, true, MT, FAST>: S is bit-identical to deflating first and building
+// S from the result.  A workgroup owns its (row block, 256 columns) region of X: no other workgroup reads or writes it.
+template <typename T, int MT, bool FAST>
+__global__ __launch_bounds__(256) void xcov_deflate_kernel(T* __restrict__ X, int64_t I, int64_t P, int B,
+                                                          const double* __restrict__ Y, int ldy, int M,
+                                                          double* __restrict__ part, int rows_per_block,
+                                                          const double* __restrict__ t, const double* __restrict__ wA,
+                                                          const double* __restrict__ wB, double* __restrict__ ssq_part) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kq = lane >> 4, nn = lane & 15;
+  const int64_t cb = ((int64_t)blockIdx.x * 4 + wv) * 64;
+  if (cb >= P) {                                         // whole wavefront past the last column
+    if (lane == 0) ssq_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = 0.0;
+    return;
+  }
+  const int64_t c = cb + 4 * nn;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < I) ? r0 + rows_per_block : I;
+  using XV = Pack<T, 4>;
+  d4_t acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[mt][e] = d4_t{0.0, 0.0, 0.0, 0.0};
+  bool mok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) mok[mt] = (mt * 16 + nn) < M;
+  constexpr int UN = CMTFPLS_XCOV_UN;
+  const bool cok = c < P;                                // (P % 4 == 0: the lane's 4 columns exist together)
+  const int64_t cc = cok ? c : P - 4;
+  int ycol[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) ycol[mt] = mok[mt] ? mt * 16 + nn : M - 1;
+  double wa[4], wb[4], ssq = 0.0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    wa[e] = wA[(cc + e) / B];
+    wb[e] = wB[(cc + e) % B];
+  }
+
+  auto load_stage = [&](XV (&x)[UN], double (&a)[UN][MT], double (&ts)[UN], int64_t r) {
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const int64_t row = r + 4 * s + kq;
+      const int64_t rowc = (FAST || row < r1) ? row : r1 - 1;
+      x[s] = ld_stream(reinterpret_cast<const XV*>(X + rowc * P + cc));
+      ts[s] = t[rowc];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[s][mt] = Y[rowc * ldy + ycol[mt]];
+    }
+  };
+  auto mma_stage = [&](XV (&x)[UN], const double (&a)[UN][MT], const double (&ts)[UN], int64_t r) {
+#pragma unroll
+    for (int s = 0; s < UN; ++s) {
+      const int64_t row = r + 4 * s + kq;
+      const bool rok = FAST || row < r1;                     // (the lane's Y values go with its ROW, whatever its columns)
+      const bool ok = rok && (FAST || cok);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double tw = ts[s] * wa[e];
+        const T nv = (T)fma(-tw, wb[e], (double)x[s].e[e]);
+        x[s].e[e] = nv;
+        const double b = (ok && nv == nv) ? (double)nv : 0.0;
+        ssq = fma(b, b, ssq);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((FAST || (rok && mok[mt])) ? a[s][mt] : 0.0, b, acc[mt][e], 0, 0, 0);
+      }
+      if (ok) st_stream(reinterpret_cast<XV*>(X + row * P + c), x[s]);
+    }
+  };
+
+  XV xa[UN], xb[UN];
+  double aa[UN][MT], ab[UN][MT], ta[UN], tb[UN];
+  load_stage(xa, aa, ta, r0);
+  for (int64_t r = r0; r < r1; r += 8 * UN) {
+    load_stage(xb, ab, tb, r + 4 * UN);     // rows past r1 are clamped on load and masked (never stored) afterwards
+    mma_stage(xa, aa, ta, r);
+    // unconditional (a load behind a branch makes the compiler wait for every load); the last trip's look-ahead re-reads this
+    // trip's own rows, already stored by this lane, and nothing uses what it returns
+    load_stage(xa, aa, ta, (r + 8 * UN >= r1) ? r : r + 8 * UN);
+    mma_stage(xb, ab, tb, r + 4 * UN);
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 0) ssq_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = ssq;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = mt * 16 + kq + 4 * g;
+      if (m < M) {
+        double* dst = part + ((int64_t)blockIdx.y * M + m) * P + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < P) dst[e] = acc[mt][e][g];
+      }
+    }
+}
+
 // du2 = (q - q_old)^T G (q - q_old):  |Y q - Y q_old|^2 with G = Y^T Y  (tpls.py:103 without
 // touching the I-long vectors)
 __global__ __launch_bounds__(256) void quadform_kernel(const double* __restrict__ G, int M, const double* __restrict__ q,
@@ -202,6 +306,36 @@ static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, 
   return rc;
 }
 
+template <typename T>
+static int run_xcov_deflate(T* X, int64_t I, int A, int B, const double* Y, int ldy, int M, const double* t, const double* wA,
+                            const double* wB, double* S, double* ssq, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!X || !Y || !S || !t || !wA || !wB || !ssq || I <= 0 || A <= 0 || B <= 0 || M <= 0 || ldy < M) {
+    set_error("xcov_deflate: bad argument");
+    return CMTFPLS_EINVAL;
+  }
+  const int64_t P = (int64_t)A * B;
+  if (M > 64 || (P % 4) != 0 || (reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) != 0) {
+    set_error("xcov_deflate: M > 64 or rows that are not whole 4-element vectors; deflate, then xcov");
+    return CMTFPLS_EUNSUPPORTED;
+  }
+  const XcovPlan p = plan_xcov(I, P);
+  const size_t need = (size_t)p.row_blocks * M * P * sizeof(double) + xcov_ssq_extra(p);
+  if (!ws || ws_bytes < need) { set_error("xcov_deflate: workspace too small"); return CMTFPLS_EWORKSPACE; }
+  const int mt = (M + 15) / 16;
+  double* part = static_cast<double*>(ws);
+  double* ssq_part = reinterpret_cast<double*>(static_cast<char*>(ws) + (size_t)p.row_blocks * M * P * sizeof(double));
+  const dim3 grid(p.col_tiles, p.row_blocks), block(256);
+  const bool fast = (P % 256 == 0) && (M % 16 == 0) && (M / 16 != 3) && (I % p.rows_per_block == 0) && (p.rows_per_block % (8 * 4) == 0);
+#define XD(MTT, FS) hipLaunchKernelGGL((xcov_deflate_kernel<T, MTT, FS>), grid, block, 0, st, X, I, P, B, Y, ldy, M, part, p.rows_per_block, t, wA, wB, ssq_part)
+  if (fast) { if (mt == 1) XD(1, true); else if (mt == 2) XD(2, true); else XD(4, true); }
+  else      { if (mt == 1) XD(1, false); else if (mt == 2) XD(2, false); else XD(4, false); }
+#undef XD
+  launch_reduce_rows(part, p.row_blocks, (int64_t)M * P, S, st);
+  int rc = check_launch("xcov_deflate");
+  if (rc == CMTFPLS_OK) rc = cmtfpls_sum_f64(ssq_part, (int64_t)p.row_blocks * p.col_tiles * 4, ssq, st);
+  return rc;
+}
+
 }  // namespace cmtfpls
 
 using namespace cmtfpls;
@@ -235,6 +369,14 @@ int cmtfpls_xcov_ssq_f64(const double* X, int64_t I, int64_t P, const double* Y,
                          double* ssq, void* ws, size_t ws_bytes, void* stream) {
   if (!mean || !ssq) { set_error("xcov_ssq: bad argument"); return CMTFPLS_EINVAL; }
   return run_xcov<double>(X, I, P, Y, ldy, M, S, 0, ws, ws_bytes, (hipStream_t)stream, mean, ssq);
+}
+int cmtfpls_xcov_deflate_f32(float* X, int64_t I, int A, int B, const double* Y, int ldy, int M, const double* t, const double* wA,
+                             const double* wB, double* S, double* ssq, void* ws, size_t ws_bytes, void* stream) {
+  return run_xcov_deflate<float>(X, I, A, B, Y, ldy, M, t, wA, wB, S, ssq, ws, ws_bytes, (hipStream_t)stream);
+}
+int cmtfpls_xcov_deflate_f64(double* X, int64_t I, int A, int B, const double* Y, int ldy, int M, const double* t, const double* wA,
+                             const double* wB, double* S, double* ssq, void* ws, size_t ws_bytes, void* stream) {
+  return run_xcov_deflate<double>(X, I, A, B, Y, ldy, M, t, wA, wB, S, ssq, ws, ws_bytes, (hipStream_t)stream);
 }
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream) {
   if (!G || !q || !q_old || !out || M <= 0) { set_error("quadform: bad argument"); return CMTFPLS_EINVAL; }

@@ -144,6 +144,9 @@ class NipalsEngine:
     # a fit on the uncentred tensor (xcov_raw): |X - X_mean|^2 from the read that builds S for the first component instead of a
     # read of its own (backend.xcov_ssq); False keeps the separate pass (tests compare the two)
     xcov_ssq_with_s = True
+    # one block WITH missing values: the deflation happens inside the rebuild of S for the next component (one read + write of X
+    # instead of a read + write and a read, FitRun._finish_xcov_masked_fused); False keeps the two passes (tests compare the two)
+    xcov_deflate_build = True
     # the inner loop on S (one NaN-free order-3 block): iteration it + 1 is ENQUEUED before the host has seen iteration it's
     # convergence norm, into a second set of buffers -- the GPU no longer idles through the status copy, the host's wake-up and
     # the next launches (FitRun._inner_loop_xcov_pipelined); False waits after every iteration (tests compare the two bit for bit)
@@ -1066,6 +1069,11 @@ class FitRun:
             else:
                 self._finish_xcov_carry(a)
             return
+        if (self.algorithm == "xcov" and len(self.blocks) == 1 and self.blocks[0].has_miss and self.S12[0] is not None
+                and a + 1 < self.R and hasattr(be, "xcov_deflate") and bool(getattr(self.eng, "xcov_deflate_build", False))
+                and getattr(self, "_deflate_build_ok", True)):
+            if self._finish_xcov_masked_fused(a):
+                return
         if self.algorithm == "xcov":
             # the final score (tpls.py:92-99 with the converged loadings) and the deflation (tpls.py:109)
             # are the only other passes over X: fused into one read + one write when there is one block
@@ -1115,6 +1123,37 @@ class FitRun:
             self.ssq_log[a, b].copy_(ssqs[b].reshape(()))                        # tpls.py:115-117 (booked in result())
         ssqy = be.y_deflate(self.Y, self.T, a + 1, b_dev, self.q)                # tpls.py:113
         self.ssq_log[a, len(self.blocks)].copy_(ssqy.reshape(()))                # tpls.py:118-120
+
+    def _finish_xcov_masked_fused(self, a: int) -> bool:
+        """finish_component of the xcov algorithm for ONE block WITH missing values, component a < R - 1.  The masked deflation
+        is not a rank-one update of S, so S (and S2) are rebuilt for every component; the rebuild reads exactly what the
+        deflation has just written.  Here the deflation happens INSIDE the rebuild: the final score (one read), then the Y
+        side (inner regression, Y deflation: they need only T and u, tpls.py:110-113), then one read + write of X that
+        deflates it (tpls.py:109) and accumulates [S; S2] = [Y, Y * rowscale]^T X0 of the deflated block and its norm on the
+        matrix cores (backend.xcov_deflate).  Three passes' worth of traffic per component instead of four.  Returns False
+        (nothing done) when the kernel does not take the shape."""
+        be, comm = self.eng.be, self.eng.comm
+        blk, M = self.blocks[0], self.M
+        if blk.A * blk.B % 4 != 0:
+            self._deflate_build_ok = False
+            return False
+        self.q = self.qc
+        be.score(self.X2[0], blk.A, blk.B, self.wA[0], self.wB[0], blk.rowcnt, self.t)      # tpls.py:92-99, masked (missingvals.py:23-38)
+        be.rowdot(self.Y, self.q, self.u, None)                                  # u = Y q (tpls.py:102)
+        self._store_component(a)
+        b_dev, _ = self._inner_regression(a)                                     # tpls.py:110-112
+        ssqy = be.y_deflate(self.Y, self.T, a + 1, b_dev, self.q)                # tpls.py:113
+        self.Yw[:, :M].copy_(self.Y)
+        torch.mul(self.Y, self.rowscale[0][:, None], out=self.Yw[:, M:])
+        ssq = be.xcov_deflate(self.X2[0], blk.A, blk.B, self.Yw, self.t, self.wA[0], self.wB[0], out=self.S12[0])
+        if ssq is None:                                                          # (nothing written) deflate now, rebuild S at start_component
+            self._deflate_build_ok = False
+            ssq = be.deflate(self.X2[0], blk.A, blk.B, self.t, self.wA[0], self.wB[0])
+        else:
+            comm.allreduce(self.S12[0])
+            self._s_ready = True
+        self._log_ssq(a, [ssq], ssqy)
+        return True
 
     def _inner_regression(self, a: int, extra: Optional[torch.Tensor] = None):
         """b = lstsq(T[:, :a+1], u) (tpls.py:110-112) from the normal equations, entirely on the device: Gram

@@ -120,6 +120,16 @@ int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int 
 int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
                      int masked, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_quadform_f64(const double* G, int M, const double* q, const double* q_old, double* out, void* stream);
+/* xcov_deflate (round 3): the deflation X -= t (x) w (tpls.py:109; NaN stays NaN, values rounded to the storage type) AND the
+ * cross-covariance S = Y^T X0 of the DEFLATED block (X0: NaN -> 0) AND ssq[0] = |X0|^2, in one read + write of X.  For blocks with
+ * missing values inside the cross-covariance loop: their S cannot be carried across a deflation algebraically, so a component
+ * cost a read + write (deflation) and a read (rebuild of S); Y is the already deflated Y (with the masked score's row rescale
+ * folded into further columns, as for cmtfpls_xcov_*).  S equals deflating first and calling cmtfpls_xcov_* (masked) bit for bit.
+ * M <= 64, A * B % 4 == 0 (CMTFPLS_EUNSUPPORTED otherwise).  ws: cmtfpls_xcov_ssq_workspace_bytes(I, A * B, M). */
+int cmtfpls_xcov_deflate_f32(float* X, int64_t I, int A, int B, const double* Y, int ldy, int M, const double* t, const double* wA,
+                             const double* wB, double* S, double* ssq, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_xcov_deflate_f64(double* X, int64_t I, int A, int B, const double* Y, int ldy, int M, const double* t, const double* wA,
+                             const double* wB, double* S, double* ssq, void* ws, size_t ws_bytes, void* stream);
 /* xcov_ssq (round 3): S as cmtfpls_xcov_* (unmasked) AND ssq[0] = sum_{i,c} (X[i,c] - mean[c])^2 from the same read of an
  * UNCENTRED X without missing values: |X - X_mean|^2, the denominator of R2X (util.py:7-20, tpls.py:115-117), for the fit that
  * never centres, writes or copies X.  (The f64 value of every element is formed for the matrix cores anyway.) */

@@ -567,6 +567,7 @@ def test_xcov_masked_fit_builds_both_cross_covariances_in_one_pass(api, monkeypa
         widths.append(Yd.shape[1])
         return orig(self, X2, Yd, *a, **k)
     monkeypatch.setattr(HipBackend, "xcov", counted)
+    monkeypatch.setattr(NipalsEngine, "xcov_deflate_build", False)          # (that form rebuilds S inside the deflation: its own test)
     one = api.tPLS(R, dtype="float32", algorithm="xcov")
     one.fit(x, y)
     assert widths == ([2 * M] * R if 2 * M <= 64 else [M] * (2 * R))
@@ -681,4 +682,58 @@ def test_xcov_raw_fit_takes_the_norm_from_the_s_build(api, monkeypatch, dtype, s
     assert_allclose(one.R2X, two.R2X, rtol=0, atol=1e-12)
     assert np.array_equal(one.X_factors[0], two.X_factors[0])
     fit = O.fit_tpls(x, y, 4)
+    assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-6 if dtype == "float32" else 1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("I,A,B,M", [(2048, 128, 128, 32), (300, 32, 64, 12), (257, 5, 52, 3), (96, 1, 1024, 64), (17, 4, 3, 8)])
+def test_xcov_deflate_kernel_equals_deflating_then_building_s(be, dtype, I, A, B, M):
+    """cmtfpls_xcov_deflate_*: X -= t (x) w in place, S = Y^T X0 of the deflated block, |X0|^2 -- bit for bit what the deflation
+    kernel followed by the masked cross-covariance kernel give."""
+    rng = np.random.default_rng(I + A + B + M)
+    x = rng.normal(size=(I, A * B))
+    x[rng.random(x.shape) < 0.25] = np.nan
+    x[5] = np.nan                                                 # an empty row
+    y, t, wA, wB = rng.normal(size=(I, M)), rng.normal(size=I), rng.normal(size=A), rng.normal(size=B)
+    X1, X2 = _dev(x).to(dtype), _dev(x).to(dtype)
+    ssq1 = be.deflate(X1, A, B, _dev(t), _dev(wA), _dev(wB))
+    S1 = be.xcov(X1, _dev(y), True, out=be.empty(M, A * B))
+    S2 = be.empty(M, A * B)
+    ssq2 = be.xcov_deflate(X2, A, B, _dev(y), _dev(t), _dev(wA), _dev(wB), out=S2)
+    assert ssq2 is not None
+    assert torch.equal(torch.isnan(X1), torch.isnan(X2)) and torch.equal(torch.nan_to_num(X1, nan=-7.0), torch.nan_to_num(X2, nan=-7.0))
+    assert torch.equal(S1, S2)
+    assert abs(float(ssq1.item()) - float(ssq2.item())) <= 1e-12 * float(ssq1.item())
+    xd = X1.double().cpu().numpy()
+    want = y.T @ np.nan_to_num(xd)
+    assert np.abs(S2.cpu().numpy() - want).max() <= 1e-12 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("dtype,shape,M", [("float32", (500, 64, 128), 16), ("float64", (300, 24, 32), 5), ("float32", (300, 7, 12), 4),
+                                           ("float64", (17, 4, 3), 4)])
+def test_xcov_masked_fit_deflates_inside_the_rebuild_of_s(api, monkeypatch, dtype, shape, M):
+    """One block with missing values: per component the final score (one read), then ONE read + write that deflates X and builds
+    [S; S2] of the next component (FitRun._finish_xcov_masked_fused) instead of a read + write and a read.  Same fit."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    R = 4 if shape[0] > 100 else 2
+    x, y, _ = O.import_synthetic(shape, M, 4, error=0.1, seed=43)
+    x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
+    if dtype == "float32":
+        x, y = _f32(x), _f32(y)
+    calls = _count_calls(monkeypatch, ["xcov", "xcov_deflate", "score_deflate"])
+    one = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    one.fit(x, y)
+    assert (calls["xcov"], calls["xcov_deflate"], calls["score_deflate"]) == (1, R - 1, 1)
+    monkeypatch.setattr(NipalsEngine, "xcov_deflate_build", False)
+    two = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    two.fit(x, y)
+    assert (calls["xcov"], calls["xcov_deflate"], calls["score_deflate"]) == (1 + R, R - 1, 1 + R)
+    assert one.n_iter_ == two.n_iter_
+    for f, g in zip(one.X_factors + one.Y_factors, two.X_factors + two.Y_factors):
+        assert _normwise(f, g) <= 1e-10
+    assert_allclose(one.R2X, two.R2X, rtol=0, atol=1e-11)
+    assert_allclose(one.R2Y, two.R2Y, rtol=0, atol=1e-11)
+    fit = O.fit_tpls(x, y, R)
+    assert one.n_iter_ == fit.n_iter
+    assert _normwise(one.X_factors[0], fit.T) <= (1e-5 if dtype == "float32" else 1e-9)
     assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-6 if dtype == "float32" else 1e-9)
