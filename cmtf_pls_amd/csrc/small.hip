@@ -167,6 +167,42 @@ __global__ __launch_bounds__(1024) void normalize_to_kernel(const double* __rest
   for (int64_t i = threadIdx.x; i < n; i += 1024) out[i] = in[i] / s;
 }
 
+// A MATRIX block's share of one inner iteration on S in ONE workgroup (cmtf.py:91-119 re-associated; three launches before):
+//   Z = sum_m q[m] S[m,:]  (masked: x n_samples / colcnt, missingvals.py:17-19),   wB = Z / |Z|  (tpls.py:84-90 for a vector Z),
+//   tq[m] = S2[m,:] . wB   (the block's Y^T t; S2 = S without missing values).
+// The loading stays in LDS between the steps (P <= 8192 doubles); wavefront w forms tq[w], tq[w + 16], ...
+__global__ __launch_bounds__(1024) void s_vector_block_kernel(const double* __restrict__ S, const double* __restrict__ S2,
+                                                            const double* __restrict__ colcnt, double n_samples, int M, int P,
+                                                            const double* __restrict__ q, double* __restrict__ Z,
+                                                            double* __restrict__ wB, double* __restrict__ tq) {
+  extern __shared__ double wl[];
+  __shared__ double red[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double ssq = 0.0;
+  for (int c = threadIdx.x; c < P; c += 1024) {
+    double z = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < M; ++m) z = fma(q[m], S[(int64_t)m * P + c], z);
+    if (colcnt) z = (colcnt[c] > 0.0) ? z / colcnt[c] * n_samples : 0.0;
+    Z[c] = z;
+    wl[c] = z;
+    ssq = fma(z, z, ssq);
+  }
+  const double nrm = sqrt(block_sum(ssq, red));
+  for (int c = threadIdx.x; c < P; c += 1024) {
+    const double w = wl[c] / nrm;
+    wl[c] = w;
+    wB[c] = w;
+  }
+  __syncthreads();
+  for (int m = wv; m < M; m += 16) {
+    double acc = 0.0;
+    for (int c = lane; c < P; c += 64) acc = fma(S2[(int64_t)m * P + c], wl[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) tq[m] = acc;
+  }
+}
+
 // The Y-side update of one NIPALS iteration in one workgroup (tpls.py:100-103):
 //   q <- sum over workgroups of qpart (the score kernel's partial sums of Y^T t)      [qpart != null]
 //   q <- q / |q|                                                                      [normalize]
@@ -451,6 +487,12 @@ int cmtfpls_xcov_iterate_blocks_f64(const cmtfpls_xcov_block* blocks, int nb, in
       return CMTFPLS_EINVAL;
     }
     const int64_t P = (int64_t)k.A * k.B;
+    if (k.order == 2 && P <= 8192) {                       // a matrix block: its whole share of the iteration in one launch
+      hipLaunchKernelGGL(s_vector_block_kernel, dim3(1), dim3(1024), (size_t)P * sizeof(double), st, k.S, k.S2 ? k.S2 : k.S, k.colcnt,
+                         k.n_samples, M, (int)P, q_cur, k.Z, k.wB, tq + (int64_t)b * M);
+      rc = check_launch("xcov_iterate_blocks: s_vector_block");
+      continue;
+    }
     if (first) {
       hipLaunchKernelGGL(s_contract_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, k.S, M, P, q_cur, k.Z);   // cmtf.py:94
       rc = check_launch("xcov_iterate_blocks: s_contract");
@@ -465,8 +507,9 @@ int cmtfpls_xcov_iterate_blocks_f64(const cmtfpls_xcov_block* blocks, int nb, in
     }
     if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(k.S2 ? k.S2 : k.S, M, k.A, k.B, k.wA, k.wB, nullptr, tq + (int64_t)b * M, stream);   // cmtf.py:106-119
   }
-  if (rc == CMTFPLS_OK && (nb > 1 || q_new != tq)) rc = cmtfpls_scores_mean_f64(tq, nb, M, q_new, stream);            // cmtf.py:120
-  if (rc == CMTFPLS_OK) rc = cmtfpls_q_update_f64(nullptr, 0, M, q_new, 1, G, q_cur, du2, stream);                   // cmtf.py:121-125
+  // cmtf.py:120-125: q_new = mean_b tq_b, normalised -- the SUM of the rows normalised is the same vector (the 1 / nb drops out of
+  // q / |q|), and summing the rows of a small matrix is what q_update does with its partials: one launch for both steps
+  if (rc == CMTFPLS_OK) rc = cmtfpls_q_update_f64(tq, nb, M, q_new, 1, G, q_cur, du2, stream);
   return rc;
 }
 

@@ -735,7 +735,7 @@ class FitRun:
 
     def inner_loop(self, a: int, max_iter: int, tol: float, verbose: int = 0) -> None:
         """The NIPALS iterations of component a (tpls.py:79-107): iterate until |u_old - u| < tol or max_iter."""
-        if self._pipeline_ok():
+        if max_iter > 0 and self._pipeline_ok():
             self._inner_loop_xcov_pipelined(a, max_iter, tol, verbose)
             return
         for it in range(max_iter):                                   # tpls.py:79
