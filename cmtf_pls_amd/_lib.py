@@ -39,6 +39,7 @@ SIGNATURES = {
     "cmtfpls_mode0_contract_yq_f64": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_colscale_f64": (c_int, [_P, c_int64, _P, c_double, _P]),
     "cmtfpls_rank1_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cmtfpls_rank1_score_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, c_size_t, _P]),
     "cmtfpls_rank1_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_normalize_f64": (c_int, [_P, c_int64, _P, _P]),
     "cmtfpls_rank1_tensor_workspace_bytes": (c_size_t, [_P, c_int]),

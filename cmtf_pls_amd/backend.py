@@ -178,6 +178,18 @@ class HipBackend:
         _lib.check(rc, "xcov_deflate")
         return ssq
 
+    def rank1_score(self, Z: torch.Tensor, A: int, B: int, wA: torch.Tensor, wB: torch.Tensor, S: torch.Tensor, tq: torch.Tensor,
+                    info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None) -> torch.Tensor:
+        """rank1(Z) -> (wA, wB), then tq = S (wA (x) wB) for the M rows of S, the extraction's last kernel and the score in one
+        launch where the shape allows (cmtfpls_rank1_score_f64)."""
+        M = S.shape[0]
+        assert S.is_contiguous() and S.shape[1] == A * B and tq.numel() >= M
+        ws = self._workspace("rank1", self.lib.cmtfpls_rank1_workspace_bytes(A, B))
+        _lib.check(self.lib.cmtfpls_rank1_score_f64(_ptr(Z), A, B, _ptr(wA), _ptr(wB), _ptr(info),
+                                                    int(n_squarings if n_squarings is not None else self.rank1_squarings),
+                                                    _ptr(S), M, _ptr(tq), _ptr(ws), ws.numel(), self._stream()), "rank1_score")
+        return tq
+
     def xcov_ssq(self, X2: torch.Tensor, Y: torch.Tensor, mean: torch.Tensor, out: torch.Tensor):
         """S = Y^T X_(0) AND sum (X - mean)^2 from one read of an uncentred, NaN-free X (cmtfpls_xcov_ssq_*); returns
         (S, ssq as a one-element device tensor), or None when M > 64."""

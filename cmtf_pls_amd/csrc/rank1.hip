@@ -339,6 +339,100 @@ __global__ __launch_bounds__(1024) void rank1_final_kernel(const double* __restr
   rank1_final_body(x, y, n, k, x_is_A, ctl, wA, wB, sigma, info);
 }
 
+// The last kernel of the extraction AND the score of a FEW LONG rows with the loading it has just formed (round 3): inside the
+// cross-covariance loop the rank-1 extraction of Z is always followed by Y^T t = S (wA (x) wB) on the M rows of S (M <= 64 rows of
+// >= 8192 elements: cmtfpls_score_f64 takes them one 1024-thread workgroup per row, score_fewrows_kernel) -- one launch of pure
+// latency less per iteration.  Every workgroup normalises and sign-fixes the two vectors itself (a few hundred elements, into
+// LDS; workgroup 0 also stores them and the flags), then takes its row exactly as score_fewrows_kernel does: same per-lane
+// order, same block sum, the same bits.
+__global__ __launch_bounds__(1024) void rank1_final_score_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                                int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
+                                                                double* __restrict__ wA, double* __restrict__ wB,
+                                                                double* __restrict__ info, const double* __restrict__ S, int A, int B,
+                                                                double* __restrict__ t) {
+  extern __shared__ double lds[];
+  __shared__ double red[2][16];
+  __shared__ double bestv[16];
+  __shared__ int besti[16];
+  double* sA = lds;
+  double* sB = lds + ((A + 1) & ~1);
+  double sx = 0.0, sy = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) sx = fma(x[i], x[i], sx);
+  for (int i = threadIdx.x; i < k; i += 1024) sy = fma(y[i], y[i], sy);
+  const double nx = sqrt(block_sum(sx, red[0]));
+  const double ny = sqrt(block_sum(sy, red[1]));
+  const double* vb = x_is_A ? y : x;                      // sign rule as rank1_final_body: wB's largest-|.| entry is positive
+  const int nb = x_is_A ? k : n;
+  double bv = -1.0;
+  int bi = 0;
+  for (int i = threadIdx.x; i < nb; i += 1024) {
+    const double d = fabs(vb[i]);
+    if (d > bv) { bv = d; bi = i; }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const double ov = __shfl_xor(bv, m, 64);
+    const int oi = __shfl_xor(bi, m, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bestv[threadIdx.x >> 6] = bv; besti[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  bv = bestv[0];
+  bi = besti[0];
+  for (int w = 1; w < 16; ++w)
+    if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
+  const double sgn = (vb[bi] < 0.0) ? -1.0 : 1.0;
+  double* lx = x_is_A ? sA : sB;
+  double* ly = x_is_A ? sB : sA;
+  double* ox = x_is_A ? wA : wB;
+  double* oy = x_is_A ? wB : wA;
+  const bool store = blockIdx.x == 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double v = sgn * (x[i] / nx);
+    lx[i] = v;
+    if (store) ox[i] = v;
+  }
+  for (int i = threadIdx.x; i < k; i += 1024) {
+    const double v = sgn * (y[i] / ny);
+    ly[i] = v;
+    if (store) oy[i] = v;
+  }
+  if (store && threadIdx.x == 0 && info) { info[0] = (ctl->done || ctl->last_step >= 0) ? 1.0 : 0.0; info[1] = (double)ctl->steps_used; }
+  __syncthreads();
+  // the row, as score_fewrows_kernel<double, false>
+  using VT = Pack<double, 2>;
+  const int64_t P = (int64_t)A * B;
+  const int64_t step = (int64_t)1024 * 2;
+  const double* __restrict__ xr = S + (int64_t)blockIdx.x * P;
+  KronWalk w((int64_t)threadIdx.x * 2, step, B);
+  double acc = 0.0;
+  int64_t c = (int64_t)threadIdx.x * 2;
+  constexpr int UN = 4;
+  for (; c + (UN - 1) * step < P; c += UN * step) {
+    VT xs[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) xs[u] = ld_stream(reinterpret_cast<const VT*>(xr + c + u * step));
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      double d = 0.0;
+      d = fma(xs[u].e[0], sB[w.k], d);
+      d = fma(xs[u].e[1], sB[w.k + 1], d);
+      acc = fma(sA[w.j], d, acc);
+      w.next();
+    }
+  }
+  for (; c < P; c += step) {
+    const VT xv = ld_stream(reinterpret_cast<const VT*>(xr + c));
+    double d = 0.0;
+    d = fma(xv.e[0], sB[w.k], d);
+    d = fma(xv.e[1], sB[w.k + 1], d);
+    acc = fma(sA[w.j], d, acc);
+    w.next();
+  }
+  acc = block_sum(acc, red[0]);
+  if (threadIdx.x == 0) t[blockIdx.x] = acc;
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace cmtfpls
@@ -354,8 +448,29 @@ size_t cmtfpls_rank1_workspace_bytes(int A, int B) {
          align_up((size_t)A * B * sizeof(double), 256) + align_up(n * sizeof(double), 256) + align_up(k * sizeof(double), 256);
 }
 
+static int rank1_run(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
+                     int n_squarings, void* ws, size_t ws_bytes, void* stream, const double* S, int M, double* tq);
+
 int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
                       int n_squarings, void* ws, size_t ws_bytes, void* stream) {
+  return rank1_run(Z, A, B, wA, wB, sigma, info, n_squarings, ws, ws_bytes, stream, nullptr, 0, nullptr);
+}
+
+int cmtfpls_rank1_score_f64(const double* Z, int A, int B, double* wA, double* wB, double* info, int n_squarings,
+                            const double* S, int M, double* tq, void* ws, size_t ws_bytes, void* stream) {
+  if (!S || !tq || M <= 0) { set_error("rank1_score: bad argument"); return CMTFPLS_EINVAL; }
+  const int64_t P = (int64_t)A * B;
+  if (M > 64 || P < 8192 || (B % 2) != 0 || ((size_t)(((A + 1) & ~1) + B) * sizeof(double)) > 60 * 1024 ||
+      (reinterpret_cast<uintptr_t>(S) & 15) != 0) {       // outside the few-long-rows form: the two entries, one after the other
+    int rc = cmtfpls_rank1_f64(Z, A, B, wA, wB, nullptr, info, n_squarings, ws, ws_bytes, stream);
+    if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(S, M, A, B, wA, wB, nullptr, tq, stream);
+    return rc;
+  }
+  return rank1_run(Z, A, B, wA, wB, nullptr, info, n_squarings, ws, ws_bytes, stream, S, M, tq);
+}
+
+static int rank1_run(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
+                     int n_squarings, void* ws, size_t ws_bytes, void* stream, const double* S, int M, double* tq) {
   if (!Z || !wA || !wB || A <= 0 || B <= 0) { set_error("rank1: bad argument"); return CMTFPLS_EINVAL; }
   const int n = A < B ? A : B, k = A < B ? B : A;
   if (n > kTile * kMaxTiles) { set_error("rank1: min(A, B) > 4096 unsupported"); return CMTFPLS_EUNSUPPORTED; }
@@ -398,6 +513,12 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
   const int ny_blocks = (k + 31) / 32;
   hipLaunchKernelGGL(rank1_seed_xy_kernel, dim3(ny_blocks + (n + 3) / 4), dim3(256), (size_t)n * sizeof(double), st,
                      M0, n, k, buf0, buf1, g0keep, ctl, n_squarings & 1, ny_blocks, yv, xv);
+  if (S) {
+    const size_t lds = (size_t)(((A + 1) & ~1) + B) * sizeof(double);
+    hipLaunchKernelGGL(rank1_final_score_kernel, dim3((unsigned)M), dim3(1024), lds, st, xv, yv, n, k, (A <= B) ? 1 : 0, ctl, wA, wB, info,
+                       S, A, B, tq);
+    return check_launch("rank1_score");
+  }
   hipLaunchKernelGGL(rank1_final_kernel, dim3(1), dim3(1024), 0, st, xv, yv, n, k, (A <= B) ? 1 : 0, ctl, wA, wB, sigma, info);
   return check_launch("rank1");
 }

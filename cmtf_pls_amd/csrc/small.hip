@@ -467,8 +467,8 @@ int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double*
     hipLaunchKernelGGL(s_contract_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, M, P, q_cur, Z);
     rc = check_launch("xcov_iterate: s_contract");
   }
-  if (rc == CMTFPLS_OK) rc = cmtfpls_rank1_f64(Z, A, B, wA, wB, nullptr, info, n_squarings, ws_rank1, ws_rank1_bytes, stream);
-  if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(S, M, A, B, wA, wB, nullptr, q_new, stream);                   // Y^T t = S (wA (x) wB)
+  // rank-1 of Z, then Y^T t = S (wA (x) wB): the extraction's last kernel and the score share a launch
+  if (rc == CMTFPLS_OK) rc = cmtfpls_rank1_score_f64(Z, A, B, wA, wB, info, n_squarings, S, M, q_new, ws_rank1, ws_rank1_bytes, stream);
   if (rc == CMTFPLS_OK) rc = cmtfpls_q_update_f64(nullptr, 0, M, q_new, 1, G, q_cur, du2, stream);            // / norm, |du|^2
   return rc;
 }
@@ -499,8 +499,10 @@ int cmtfpls_xcov_iterate_blocks_f64(const cmtfpls_xcov_block* blocks, int nb, in
       if (rc == CMTFPLS_OK && k.colcnt) rc = cmtfpls_colscale_f64(k.Z, P, k.colcnt, k.n_samples, stream);             // missingvals.py:17-19
     }
     if (rc != CMTFPLS_OK) break;
-    if (k.order == 3) {
-      rc = cmtfpls_rank1_f64(k.Z, k.A, k.B, k.wA, k.wB, nullptr, k.info, k.n_squarings, ws_rank1, ws_rank1_bytes, stream);   // cmtf.py:98-104
+    if (k.order == 3) {                                    // cmtf.py:98-104, then cmtf.py:106-119 on S2 (same launch when the shape allows)
+      rc = cmtfpls_rank1_score_f64(k.Z, k.A, k.B, k.wA, k.wB, k.info, k.n_squarings, k.S2 ? k.S2 : k.S, M, tq + (int64_t)b * M, ws_rank1,
+                                   ws_rank1_bytes, stream);
+      continue;
     } else {
       hipLaunchKernelGGL(normalize_to_kernel, dim3(1), dim3(1024), 0, st, k.Z, k.wB, P);
       rc = check_launch("xcov_iterate_blocks: normalize_to");

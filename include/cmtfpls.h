@@ -95,6 +95,12 @@ int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_sa
 size_t cmtfpls_rank1_workspace_bytes(int A, int B);
 int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
                       int n_squarings, void* ws, size_t ws_bytes, void* stream);
+/* rank1 followed by the score of the M rows of S with the loading just formed, tq[m] = S[m,:] . (wA (x) wB) -- the pair every
+ * iteration of the cross-covariance loop issues (tpls.py:84-90, then Y^T t = S w) -- with the extraction's last kernel and the
+ * score in ONE launch when S has M <= 64 rows of >= 8192 elements (B even); any other shape runs the two entries one after the
+ * other.  Same results as cmtfpls_rank1_f64 + cmtfpls_score_f64, bit for bit. */
+int cmtfpls_rank1_score_f64(const double* Z, int A, int B, double* wA, double* wB, double* info, int n_squarings,
+                            const double* S, int M, double* tq, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_normalize_f64(double* v, int64_t n, double* nrm, void* stream);
 /* rank1_tensor: the same parafac call when Z is a TENSOR of order n = 3 .. 7 (X of order 4 .. 8; orders 4 and 5 are
  * exercised by tests/test_cmtf.py:18-21, tests/test_tpls.py:132-155): leading-left-singular-vector

@@ -737,3 +737,21 @@ def test_xcov_masked_fit_deflates_inside_the_rebuild_of_s(api, monkeypatch, dtyp
     assert one.n_iter_ == fit.n_iter
     assert _normwise(one.X_factors[0], fit.T) <= (1e-5 if dtype == "float32" else 1e-9)
     assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-6 if dtype == "float32" else 1e-9)
+
+
+@pytest.mark.parametrize("A,B,M", [(128, 128, 16), (64, 256, 5), (256, 64, 32), (16, 512, 64), (128, 130, 3), (32, 64, 4), (128, 127, 4)])
+def test_rank1_score_equals_rank1_then_score_bit_for_bit(be, A, B, M):
+    """cmtfpls_rank1_score_f64: the extraction's last kernel and the score of the M rows of S in one launch (rows of >= 8192
+    elements, B even; other shapes run the two entries) -- the same loadings and the same scores, bit for bit."""
+    rng = np.random.default_rng(A + B + M)
+    z = np.outer(rng.normal(size=A), rng.normal(size=B)) * 3.0 + 0.5 * rng.normal(size=(A, B))
+    S = _dev(rng.normal(size=(M, A * B)))
+    Z = _dev(z.reshape(-1))
+    w1, v1, i1, t1 = be.empty(A), be.empty(B), be.zeros(2), be.empty(M)
+    be.rank1(Z, A, B, w1, v1, info=i1)
+    be.score(S, A, B, w1, v1, None, t1)
+    w2, v2, i2, t2 = be.empty(A), be.empty(B), be.zeros(2), be.empty(M)
+    be.rank1_score(Z, A, B, w2, v2, S, t2, info=i2)
+    assert torch.equal(w1, w2) and torch.equal(v1, v2) and torch.equal(i1, i2) and torch.equal(t1, t2)
+    u, s, vt = np.linalg.svd(z)
+    assert abs(abs(w2.cpu().numpy() @ u[:, 0]) - 1.0) < 1e-12
