@@ -117,6 +117,35 @@ class NumpyBackend:
             self.q_update(q_new, None, True, G, q_cur, status[0:1])
         return enqueue
 
+    # -- the uncentred ("raw") cross-covariance fit and the fused masked deflation: contracts of include/cmtfpls.h ----------------
+    def axpy_scalar(self, y, a, x=None):
+        y -= float(a[0]) * (x if x is not None else 1.0)
+        return y
+
+    def total(self, v):
+        return torch.tensor([float(v.sum())], dtype=torch.float64)
+
+    def recon_r2(self, X2, T, WA, WB, mean):
+        x = _np(X2).astype(np.float64) - (_np(mean) if mean is not None else 0.0)
+        W = (_np(WA)[:, None, :] * _np(WB)[None, :, :]).reshape(x.shape[1], -1)
+        xhat = _np(T) @ W.T
+        ok = np.isfinite(x)
+        return torch.tensor([float(((xhat - x)[ok] ** 2).sum()), float((x[ok] ** 2).sum())], dtype=torch.float64)
+
+    def xcov_ssq(self, X2, Y, mean, out):
+        if Y.shape[1] > 64:
+            return None
+        x = _np(X2).astype(np.float64)
+        out.copy_(torch.from_numpy(_np(Y).T @ x))
+        return out, torch.tensor([float(((x - _np(mean)) ** 2).sum())], dtype=torch.float64)
+
+    def xcov_deflate(self, X2, A, B, Y, t, wA, wB, out):
+        if X2.shape[1] % 4 != 0 or Y.shape[1] > 64:
+            return None        # (the HIP kernel takes whole 4-element vectors only: the engine must deflate, then rebuild)
+        ssq = self.deflate(X2, A, B, t, wA, wB)
+        self.xcov(X2, Y, True, out=out)
+        return ssq
+
     def status_snapshot(self, status, slot):
         return status.clone().numpy()
 

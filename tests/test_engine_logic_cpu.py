@@ -244,8 +244,9 @@ def test_xcov_without_writing_x_equals_the_deflating_form(case, monkeypatch):
     assert np.all(np.isfinite(b.coef_)) and np.all(np.isfinite(Tb))
     if len(Xs) == 1:                                   # (a coupled fit's R2Xs need not increase: tests/test_cmtf.py:27,39)
         assert np.all(np.diff(r2b[0]) >= -1e-9) and r2b[0][-1] <= 1 + 1e-9        # the norm recurrence stays monotone and <= 1
-    # the never-write fit leaves its working copy as centred
+    # the never-write fit leaves its working copy as centred (with `xcov_raw` it would not even be centred: the next test)
     monkeypatch.setattr(NipalsEngine, "xcov_nowrite", True)
+    monkeypatch.setattr(NipalsEngine, "xcov_raw", False)
     import torch
     Xd = torch.from_numpy(Xs[0].copy())
     m = (ctPLS if len(Xs) > 1 else tPLS)(R, backend=NumpyBackend(), algorithm="xcov", copy_X=False)
@@ -316,6 +317,49 @@ def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
         np.testing.assert_allclose(r1, r2, rtol=0, atol=1e-10)
     np.testing.assert_allclose(one.R2Y[:ncmp], two.R2Y[:ncmp], rtol=0, atol=1e-10)
     np.testing.assert_allclose(one.coef_[:ncmp, :ncmp], two.coef_[:ncmp, :ncmp], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("case", ["tpls3", "coupled", "matrix"])
+def test_xcov_on_the_uncentred_tensor_equals_the_centred_form_cpu(case, monkeypatch):
+    """NipalsEngine.xcov_raw through the NumPy backend: the fit reads the caller's uncentred blocks (never written, never centred)
+    and applies the centring algebraically; |X - X_mean|^2 comes out of the S-build read (xcov_ssq).  Same fit as on centred copies."""
+    from cmtf_pls_amd.engine import NipalsEngine
+    import torch
+    rng = np.random.default_rng(5)
+    x, y, cp = O.import_synthetic((40, 6, 5), 3, 3, error=0.2, seed=8)
+    x = x + 5.0
+    xm = cp.factors[0] @ rng.normal(size=(7, 3)).T - 2.0
+    blocks = {"tpls3": [x], "coupled": [x, xm], "matrix": [xm]}[case]
+    coupled = len(blocks) > 1
+    calls = {"xcov_ssq": 0, "center": 0}
+    for name in calls:
+        orig = getattr(NumpyBackend, name)
+
+        def counted(self, *a, __orig=orig, __name=name, **k):
+            calls[__name] += 1
+            return __orig(self, *a, **k)
+        monkeypatch.setattr(NumpyBackend, name, counted)
+
+    def fit(raw):
+        monkeypatch.setattr(NipalsEngine, "xcov_raw", raw)
+        held = [torch.from_numpy(b.copy()) for b in blocks]
+        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov", copy_X=False)
+        m.fit(held if coupled else held[0], y)
+        return m, held
+
+    raw, held = fit(True)
+    assert calls["xcov_ssq"] == len(blocks) and calls["center"] == 1          # (the one centring call is Y's)
+    for h, b in zip(held, blocks):
+        assert np.array_equal(h.numpy(), b)                                    # the caller's blocks: same bits afterwards
+    cen, _ = fit(False)
+    assert raw.n_iter_ == cen.n_iter_
+    f1 = ([raw.factor_T] + [f for fs in raw.Xs_factors for f in fs[1:]]) if coupled else raw.X_factors
+    f2 = ([cen.factor_T] + [f for fs in cen.Xs_factors for f in fs[1:]]) if coupled else cen.X_factors
+    for f, g in zip(f1 + list(raw.Y_factors), f2 + list(cen.Y_factors)):
+        np.testing.assert_allclose(f, g, rtol=1e-9, atol=1e-10)
+    for a, b in zip(raw.R2Xs if coupled else [raw.R2X], cen.R2Xs if coupled else [cen.R2X]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(raw.R2Y, cen.R2Y, rtol=0, atol=1e-10)
 
 
 class _StingyBackend(NumpyBackend):

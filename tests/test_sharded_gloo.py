@@ -39,22 +39,24 @@ def _worker(rank, world, port, case, ret):
         from numpy_backend import NumpyBackend
 
         x, y, cp = O.import_synthetic((60, 8, 6), 3, 3, error=0.1, seed=21)
-        if case == "nan":
+        if case in ("nan", "xcov_nan"):
             x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
+        if case == "xcov_raw":
+            x = x + 4.0                                      # (the uncentred form's corrections are summed over the ranks)
         if world == 2:
             rows = slice(rank * 30, (rank + 1) * 30)
         else:                                                # uneven shards: 13 / 20 / 27 rows on 3 ranks
             cuts = [0, 13, 33, 60]
             rows = slice(cuts[rank], cuts[rank + 1])
-        if case == "coupled":
+        if case in ("coupled", "xcov_coupled"):
             xm = cp.factors[0] @ np.random.default_rng(4).normal(size=(9, 3)).T
-            m = ctPLS(3, backend=NumpyBackend(), comm=Comm())
+            m = ctPLS(3, backend=NumpyBackend(), comm=Comm(), algorithm="xcov" if case == "xcov_coupled" else "direct")
             m.fit([x[rows], xm[rows]], y[rows])
             fit = O.fit_ctpls([x, xm], y, 3)
             T, loads = m.factor_T, m.Xs_factors[0][1:]
             r2x = m.R2Xs[0]
         else:
-            m = tPLS(3, backend=NumpyBackend(), comm=Comm(), algorithm="xcov" if case == "xcov" else "direct")
+            m = tPLS(3, backend=NumpyBackend(), comm=Comm(), algorithm="xcov" if case.startswith("xcov") else "direct")
             m.fit(x[rows], y[rows])
             fit = O.fit_tpls(x, y, 3)
             T, loads = m.X_factors[0], m.X_factors[1:]
@@ -69,7 +71,7 @@ def _worker(rank, world, port, case, ret):
         np.testing.assert_allclose(m.R2Y, fit.r2y, rtol=1e-6, atol=1e-9)
         assert list(m.n_iter_) == list(fit.n_iter)
         # transform of the local rows needs no communication
-        if case != "coupled":
+        if case not in ("coupled", "xcov_coupled"):
             np.testing.assert_allclose(m.transform(x[rows]), fit.T[rows], rtol=1e-6, atol=1e-8)
         ret[rank] = "ok"
     except Exception as e:  # noqa: BLE001
@@ -79,7 +81,7 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["plain", "nan", "coupled", "xcov"])
+@pytest.mark.parametrize("case", ["plain", "nan", "coupled", "xcov", "xcov_nan", "xcov_coupled", "xcov_raw"])
 def test_world2_matches_oracle(case):
     world = 2
     with mp.Manager() as mgr:
