@@ -75,12 +75,12 @@ def _worker(rank, world, port, case, ret):
             ret[rank] = "ok"
             return
         x, y, _ = O.import_synthetic((512, 16, 12), 4, 3, error=0.2, seed=23)
-        if case == "nan":
+        if case in ("nan", "xcov_nan"):
             x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
         half = 256
         rows = slice(rank * half, (rank + 1) * half)
         fit = O.fit_tpls(x, y, 3)
-        algorithm = "xcov" if case == "xcov" else "direct"
+        algorithm = "xcov" if case in ("xcov", "xcov_nan") else "direct"     # xcov_nan: S and S2 rebuilt inside the deflation, summed over ranks
         m = tPLS(3, device="cuda:0", comm=Comm(), algorithm=algorithm, graphs=(case == "graphs"))
         m.fit(x[rows], y[rows])
         s = np.abs(fit.T).max()
@@ -111,7 +111,7 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["plain", "nan", "xcov", "graphs", "xcov_long_rows", "xcov_coupled"])
+@pytest.mark.parametrize("case", ["plain", "nan", "xcov", "xcov_nan", "graphs", "xcov_long_rows", "xcov_coupled"])
 def test_two_ranks_one_gpu(case):
     world = 2
     with mp.Manager() as mgr:
