@@ -29,6 +29,7 @@ class HipBackend:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.n_partials = int(self.lib.cmtfpls_sweep_partials())
         self._ws = {}
+        self._status_slots = {}        # (slot, words) -> pinned host buffer + event of status_snapshot
         self.rank1_squarings = 30      # budget ceiling: resolves sigma_2/sigma_1 up to 1 - 1e-8
 
     # -- helpers ---------------------------------------------------------------------------
@@ -207,7 +208,7 @@ class HipBackend:
     def status_snapshot(self, status: torch.Tensor, slot: int):
         """Enqueue a copy of a few status words to pinned host memory behind the work issued so far (cmtfpls_status_to_host);
         returns a token for status_wait.  (slot: the caller keeps at most one snapshot per slot in flight.)"""
-        slots = self.__dict__.setdefault("_status_slots", {})
+        slots = self._status_slots
         ent = slots.get((slot, status.numel()))
         if ent is None:
             host, ev = torch.empty(status.numel(), dtype=torch.float64, pin_memory=True), torch.cuda.Event()

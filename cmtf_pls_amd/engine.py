@@ -25,7 +25,6 @@ from __future__ import annotations
 
 import contextlib
 import math
-import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -839,8 +838,6 @@ class FitRun:
                     self.sq_budget[b] = self.sq_max
                 tok = enqueue(it, first=False)
                 stats["redone"] += 1
-                if os.environ.get("CMTFPLS_PIPELINE_DEBUG"):
-                    print(f"  pipeline: component {a} iteration {it} redone (blocks {short})", flush=True)
                 continue
             for b, blk in enumerate(self.blocks):
                 if len(blk.shape) == 3 and host[1 + 2 * b] > 0.5:

@@ -146,8 +146,9 @@ int cmtfpls_xcov_ssq_f64(const double* X, int64_t I, int64_t P, const double* Y,
                          double* ssq, void* ws, size_t ws_bytes, void* stream);
 /* One inner iteration of the loop on S (tpls.py:80-103 re-associated) issued by a single host call:
  * Z = sum_m q_cur[m] S[m,:] (only if first != 0), rank1(Z) -> (wA, wB, info), q_new = S (wA (x) wB) normalised,
- * du2 = (q_new - q_cur)^T G (q_new - q_cur).  Same kernels as the separate entries; workspaces as
- * cmtfpls_mode0_contract_workspace_bytes(M, A*B) and cmtfpls_rank1_workspace_bytes(A, B).  M <= 64. */
+ * du2 = (q_new - q_cur)^T G (q_new - q_cur).  Same results as the separate entries (since round 3 the contraction of the M-row S is
+ * one launch without partial rows, and the extraction's last kernel shares a launch with the score: cmtfpls_rank1_score_f64);
+ * ws_rank1 as cmtfpls_rank1_workspace_bytes(A, B); ws_contract is no longer used (kept in the signature).  M <= 64. */
 int cmtfpls_xcov_iterate_f64(const double* S, int M, int A, int B, const double* q_cur, double* Z, double* wA,
                              double* wB, double* info, int n_squarings, double* q_new, const double* G, double* du2,
                              int first, void* ws_contract, size_t ws_contract_bytes, void* ws_rank1,
