@@ -55,6 +55,10 @@ SIGNATURES = {
     "cmtfpls_project_rows_f64": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "cmtfpls_project_rows2_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P]),
     "cmtfpls_project_rows2_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P]),
+    "cmtfpls_project_rows_idx_f32": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "cmtfpls_project_rows_idx_f64": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "cmtfpls_project_rows2_idx_f32": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P]),
+    "cmtfpls_project_rows2_idx_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P]),
     "cmtfpls_allreduce_sum_f64": (c_int, [_P, _P, c_size_t, _P]),
     "cmtfpls_allreduce_sum_f32": (c_int, [_P, _P, c_size_t, _P]),
     "cmtfpls_axpy_scalar_f64": (c_int, [_P, c_int64, _P, _P, _P]),

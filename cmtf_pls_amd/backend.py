@@ -150,11 +150,9 @@ class HipBackend:
     def xcov(self, X2: torch.Tensor, Y: torch.Tensor, masked: bool, out: Optional[torch.Tensor] = None,
              mixed: bool = False) -> Optional[torch.Tensor]:
         """S (M, P) = Y^T X_(0) on the matrix cores (f64 MFMA; ``mixed`` = the opt-in f32-MFMA form for
-        f32-stored X); None when M > 64 (caller uses the direct loop)."""
+        f32-stored X).  More than 64 responses: tiles of 64, one pass over X each (inside the C entry)."""
         I, P = X2.shape
         M = Y.shape[1]
-        if M > 64:
-            return None
         ws = self._workspace("contract", self.lib.cmtfpls_xcov_workspace_bytes(I, P, M))
         S = out if out is not None else self.empty(M, P)
         fn = self.lib.cmtfpls_xcov_f32_mixed if (mixed and X2.dtype == torch.float32) else self._fn("xcov", X2)
@@ -193,11 +191,9 @@ class HipBackend:
 
     def xcov_ssq(self, X2: torch.Tensor, Y: torch.Tensor, mean: torch.Tensor, out: torch.Tensor):
         """S = Y^T X_(0) AND sum (X - mean)^2 from one read of an uncentred, NaN-free X (cmtfpls_xcov_ssq_*); returns
-        (S, ssq as a one-element device tensor), or None when M > 64."""
+        (S, ssq as a one-element device tensor).  More than 64 responses: tiles of 64, the norm from the first pass."""
         I, P = X2.shape
         M = Y.shape[1]
-        if M > 64:
-            return None
         ws = self._workspace("contract", self.lib.cmtfpls_xcov_ssq_workspace_bytes(I, P, M))
         ssq = self.empty(1)
         assert mean.is_contiguous() and mean.numel() == P and mean.dtype == torch.float64
@@ -205,10 +201,12 @@ class HipBackend:
                                             self._stream()), "xcov_ssq")
         return out, ssq
 
-    def status_snapshot(self, status: torch.Tensor, slot: int):
+    def status_snapshot(self, status: torch.Tensor, slot: int, slots: Optional[dict] = None):
         """Enqueue a copy of a few status words to pinned host memory behind the work issued so far (cmtfpls_status_to_host);
-        returns a token for status_wait.  (slot: the caller keeps at most one snapshot per slot in flight.)"""
-        slots = self._status_slots
+        returns a token for status_wait.  (slot: the caller keeps at most one snapshot per slot in flight.)  `slots`: the
+        CALLER's cache of pinned buffers and events -- a fit in flight owns its own (FitRun._pipe), so two fits on one
+        backend (other threads, other streams) never share a buffer; None: the backend's own, for single-threaded tools."""
+        slots = self._status_slots if slots is None else slots
         ent = slots.get((slot, status.numel()))
         if ent is None:
             host, ev = torch.empty(status.numel(), dtype=torch.float64, pin_memory=True), torch.cuda.Event()
@@ -475,27 +473,38 @@ class HipBackend:
         return out
 
     def project_rows(self, X2: torch.Tensor, A: int, B: int, WA: torch.Tensor, WB: torch.Tensor, mean: Optional[torch.Tensor],
-                     out: torch.Tensor) -> Optional[torch.Tensor]:
-        """out (I, R) = the R sequential masked project-and-deflate steps of every row of the UNCENTRED X2, the row kept in
-        registers (one read, nothing written); None when the shape is outside that form."""
+                     out: torch.Tensor, rows: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """out (I, R) = the R sequential masked project-and-deflate steps of every row of the UNCENTRED X2 -- or of the rows
+        listed in `rows` (int64 device tensor) only, the others left as they are -- the row kept in registers (one read,
+        nothing written); None when the shape is outside that form."""
         I, R = X2.shape[0], WA.shape[1]
         assert WA.is_contiguous() and WB.is_contiguous() and out.stride(1) == 1 and out.shape == (I, R)
-        rc = self._fn("project_rows", X2)(_ptr(X2), I, A, B, R, _ptr(WA), _ptr(WB), _ptr(mean), _ptr(out), out.stride(0), self._stream())
+        if rows is not None:
+            assert rows.dtype == torch.int64 and rows.is_contiguous() and rows.device == self.device
+            rc = self._fn("project_rows_idx", X2)(_ptr(X2), _ptr(rows), rows.numel(), A, B, R, _ptr(WA), _ptr(WB), _ptr(mean), _ptr(out),
+                                                  out.stride(0), self._stream())
+        else:
+            rc = self._fn("project_rows", X2)(_ptr(X2), I, A, B, R, _ptr(WA), _ptr(WB), _ptr(mean), _ptr(out), out.stride(0), self._stream())
         if rc == 4:
             return None
         _lib.check(rc, "project_rows")
         return out
 
-    def project_rows2(self, X2s, As, Bs, WAs, WBs, means, out: torch.Tensor) -> Optional[torch.Tensor]:
+    def project_rows2(self, X2s, As, Bs, WAs, WBs, means, out: torch.Tensor, rows: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """project_rows for TWO COUPLED blocks (lists of two): the sample's row of both blocks in one workgroup, the score
-        of every step the mean of the two masked block scores (cmtf.py:155,206); None outside that form."""
+        of every step the mean of the two masked block scores (cmtf.py:155,206); `rows` as in project_rows; None outside
+        that form."""
         I, R = X2s[0].shape[0], WAs[0].shape[1]
         if X2s[0].dtype != X2s[1].dtype or X2s[1].shape[0] != I:
             return None
         assert all(w.is_contiguous() for w in list(WAs) + list(WBs)) and out.stride(1) == 1 and out.shape == (I, R)
-        rc = self._fn("project_rows2", X2s[0])(_ptr(X2s[0]), As[0], Bs[0], _ptr(WAs[0]), _ptr(WBs[0]), _ptr(means[0]),
-                                               _ptr(X2s[1]), As[1], Bs[1], _ptr(WAs[1]), _ptr(WBs[1]), _ptr(means[1]),
-                                               I, R, _ptr(out), out.stride(0), self._stream())
+        head = (_ptr(X2s[0]), As[0], Bs[0], _ptr(WAs[0]), _ptr(WBs[0]), _ptr(means[0]),
+                _ptr(X2s[1]), As[1], Bs[1], _ptr(WAs[1]), _ptr(WBs[1]), _ptr(means[1]))
+        if rows is not None:
+            assert rows.dtype == torch.int64 and rows.is_contiguous() and rows.device == self.device
+            rc = self._fn("project_rows2_idx", X2s[0])(*head, _ptr(rows), rows.numel(), R, _ptr(out), out.stride(0), self._stream())
+        else:
+            rc = self._fn("project_rows2", X2s[0])(*head, I, R, _ptr(out), out.stride(0), self._stream())
         if rc == 4:
             return None
         _lib.check(rc, "project_rows2")

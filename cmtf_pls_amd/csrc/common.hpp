@@ -150,6 +150,7 @@ struct XcovPlan {
   int col_tiles, row_blocks, rows_per_block;
 };
 XcovPlan plan_xcov(int64_t I, int64_t P);
+constexpr int kXcovMaxResponses = 64;       // accumulators of one pass (4 tiles of 16 per wavefront); more responses: more passes
 
 void set_error(const char* msg);
 int check_launch(const char* what);

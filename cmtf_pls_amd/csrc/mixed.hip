@@ -319,7 +319,14 @@ extern "C" {
 int cmtfpls_xcov_f32_mixed(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
                            void* ws, size_t ws_bytes, void* stream) {
   if (!X || !Y || !S || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov_mixed: bad argument"); return CMTFPLS_EINVAL; }
-  if (M > 64) { set_error("xcov_mixed: more than 64 responses"); return CMTFPLS_EUNSUPPORTED; }
+  if (M > kXcovMaxResponses) {                            // tiles of <= 64 responses, one pass over X each (as cmtfpls_xcov_*)
+    for (int lo = 0; lo < M; lo += kXcovMaxResponses) {
+      const int mt = (M - lo < kXcovMaxResponses) ? M - lo : kXcovMaxResponses;
+      const int rc = cmtfpls_xcov_f32_mixed(X, I, P, Y + lo, ldy, mt, S + (int64_t)lo * P, masked, ws, ws_bytes, stream);
+      if (rc != CMTFPLS_OK) return rc;
+    }
+    return CMTFPLS_OK;
+  }
   const XcovPlan p = plan_xcov(I, P);
   const size_t need = (size_t)p.row_blocks * M * P * sizeof(double);
   if (!ws || ws_bytes < need) { set_error("xcov_mixed: workspace too small"); return CMTFPLS_EWORKSPACE; }

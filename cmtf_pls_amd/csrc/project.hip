@@ -124,7 +124,7 @@ struct RowPart {
 // left alone the allocator takes 132)
 template <typename T, int NT, int NV0, int NV1>
 __global__ __launch_bounds__(NT, (NT == 256 && NV0 == 16 && NV1 == 0) ? 4 : 1) void project_rows_kernel(ProjBlock<T> b0, ProjBlock<T> b1, int64_t I, int R,
-                                                         double* __restrict__ scores, int ld) {
+                                                         double* __restrict__ scores, int ld, const int64_t* __restrict__ rows) {
   extern __shared__ double lds[];                    // sA0[R][A0] | sB0[R][B0] | sA1[R][A1] | sB1[R][B1]
   constexpr int NW = NT / 64;
   constexpr int V = VecOf<T>::N;
@@ -147,7 +147,10 @@ __global__ __launch_bounds__(NT, (NT == 256 && NV0 == 16 && NV1 == 0) ? 4 : 1) v
   if (TWO) p1.init(b1.A, b1.B);
   __syncthreads();
   int parity = 0;
-  for (int64_t row = blockIdx.x; row < I; row += gridDim.x) {
+  // rows != null: only the listed samples (the ones WITH a missing value inside a batch whose complete samples keep their
+  // one-pass MTTKRP scores); I is then the length of the list and scores is still indexed by the sample
+  for (int64_t it = blockIdx.x; it < I; it += gridDim.x) {
+    const int64_t row = rows ? rows[it] : it;
     p0.load(b0.X, row);
     if (TWO) p1.load(b1.X, row);
     double cnt0 = wave_sum(p0.centre_count(b0.mean));
@@ -208,7 +211,8 @@ static bool block_fits(const ProjBlock<T>& b, int NT, int max_nv, int* nv_out) {
 }
 
 template <typename T>
-static int run_project_rows(ProjBlock<T> b0, ProjBlock<T> b1, int nblocks, int64_t I, int R, double* scores, int ld, hipStream_t st) {
+static int run_project_rows(ProjBlock<T> b0, ProjBlock<T> b1, int nblocks, int64_t I, int R, double* scores, int ld, hipStream_t st,
+                            const int64_t* rows = nullptr) {
   if (nblocks < 1 || nblocks > 2 || !b0.X || !b0.WA || !b0.WB || !scores || I <= 0 || b0.A <= 0 || b0.B <= 0 || R <= 0 || ld < R ||
       (nblocks == 2 && (!b1.X || !b1.WA || !b1.WB || b1.A <= 0 || b1.B <= 0))) {
     set_error("project_rows: bad argument");
@@ -224,7 +228,7 @@ static int run_project_rows(ProjBlock<T> b0, ProjBlock<T> b1, int nblocks, int64
     if (lds + 1024 > 64 * 1024)                                                                                          \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(project_rows_kernel<T, NTT, NVA, NVB>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-    hipLaunchKernelGGL((project_rows_kernel<T, NTT, NVA, NVB>), g, dim3(NTT), lds, st, b0, b1, I, R, scores, ld);        \
+    hipLaunchKernelGGL((project_rows_kernel<T, NTT, NVA, NVB>), g, dim3(NTT), lds, st, b0, b1, I, R, scores, ld, rows);  \
   } while (0)
   int nv0 = 0, nv1 = 0;
   if (nblocks == 1) {
@@ -270,6 +274,36 @@ int cmtfpls_project_rows_f64(const double* X, int64_t I, int A, int B, int R, co
                              double* scores, int ld, void* stream) {
   return run_project_rows<double>(ProjBlock<double>{X, WA, WB, mean, A, B}, ProjBlock<double>{nullptr, nullptr, nullptr, nullptr, 0, 0}, 1, I, R,
                                   scores, ld, (hipStream_t)stream);
+}
+int cmtfpls_project_rows_idx_f32(const float* X, const int64_t* rows, int64_t n_rows, int A, int B, int R, const double* WA, const double* WB,
+                                 const double* mean, double* scores, int ld, void* stream) {
+  if (!rows) { set_error("project_rows_idx: bad argument"); return CMTFPLS_EINVAL; }
+  if (n_rows == 0) return CMTFPLS_OK;
+  return run_project_rows<float>(ProjBlock<float>{X, WA, WB, mean, A, B}, ProjBlock<float>{nullptr, nullptr, nullptr, nullptr, 0, 0}, 1, n_rows, R,
+                                 scores, ld, (hipStream_t)stream, rows);
+}
+int cmtfpls_project_rows_idx_f64(const double* X, const int64_t* rows, int64_t n_rows, int A, int B, int R, const double* WA, const double* WB,
+                                 const double* mean, double* scores, int ld, void* stream) {
+  if (!rows) { set_error("project_rows_idx: bad argument"); return CMTFPLS_EINVAL; }
+  if (n_rows == 0) return CMTFPLS_OK;
+  return run_project_rows<double>(ProjBlock<double>{X, WA, WB, mean, A, B}, ProjBlock<double>{nullptr, nullptr, nullptr, nullptr, 0, 0}, 1, n_rows, R,
+                                  scores, ld, (hipStream_t)stream, rows);
+}
+int cmtfpls_project_rows2_idx_f32(const float* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
+                                  const float* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,
+                                  const int64_t* rows, int64_t n_rows, int R, double* scores, int ld, void* stream) {
+  if (!rows) { set_error("project_rows2_idx: bad argument"); return CMTFPLS_EINVAL; }
+  if (n_rows == 0) return CMTFPLS_OK;
+  return run_project_rows<float>(ProjBlock<float>{X0, WA0, WB0, mean0, A0, B0}, ProjBlock<float>{X1, WA1, WB1, mean1, A1, B1}, 2, n_rows, R,
+                                 scores, ld, (hipStream_t)stream, rows);
+}
+int cmtfpls_project_rows2_idx_f64(const double* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
+                                  const double* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,
+                                  const int64_t* rows, int64_t n_rows, int R, double* scores, int ld, void* stream) {
+  if (!rows) { set_error("project_rows2_idx: bad argument"); return CMTFPLS_EINVAL; }
+  if (n_rows == 0) return CMTFPLS_OK;
+  return run_project_rows<double>(ProjBlock<double>{X0, WA0, WB0, mean0, A0, B0}, ProjBlock<double>{X1, WA1, WB1, mean1, A1, B1}, 2, n_rows, R,
+                                  scores, ld, (hipStream_t)stream, rows);
 }
 int cmtfpls_project_rows2_f32(const float* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
                               const float* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,

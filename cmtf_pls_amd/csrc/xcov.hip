@@ -273,10 +273,8 @@ __global__ __launch_bounds__(256) void quadform_kernel(const double* __restrict_
 static size_t xcov_ssq_extra(const XcovPlan& p) { return ((size_t)p.row_blocks * p.col_tiles * 4 * sizeof(double) + 255) / 256 * 256; }
 
 template <typename T>
-static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
-                    void* ws, size_t ws_bytes, hipStream_t st, const double* mean = nullptr, double* ssq_out = nullptr) {
-  if (!X || !Y || !S || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov: bad argument"); return CMTFPLS_EINVAL; }
-  if (M > 64) { set_error("xcov: more than 64 responses; use the direct algorithm"); return CMTFPLS_EUNSUPPORTED; }
+static int run_xcov_tile(const T* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
+                         void* ws, size_t ws_bytes, hipStream_t st, const double* mean = nullptr, double* ssq_out = nullptr) {
   const XcovPlan p = plan_xcov(I, P);
   const bool with_ssq = ssq_out != nullptr;
   if (with_ssq && (masked || !mean)) { set_error("xcov_ssq: needs the column means and a block without missing values"); return CMTFPLS_EINVAL; }
@@ -304,6 +302,21 @@ static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, 
   int rc = check_launch("xcov");
   if (rc == CMTFPLS_OK && with_ssq) rc = cmtfpls_sum_f64(ssq_part, (int64_t)p.row_blocks * p.col_tiles * 4, ssq_out, st);
   return rc;
+}
+
+// The kernel holds the accumulators of <= 64 responses (4 tiles of 16) per wavefront.  The reference has no limit on the number
+// of responses (tpls.py:100-102): more of them are served in tiles of <= 64 columns of Y, one pass over X each, into the
+// matching rows of S, through the same workspace (the passes are ordered on the stream); the norm comes out of the first pass.
+template <typename T>
+static int run_xcov(const T* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
+                    void* ws, size_t ws_bytes, hipStream_t st, const double* mean = nullptr, double* ssq_out = nullptr) {
+  if (!X || !Y || !S || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov: bad argument"); return CMTFPLS_EINVAL; }
+  for (int lo = 0; lo < M; lo += kXcovMaxResponses) {
+    const int mt = (M - lo < kXcovMaxResponses) ? M - lo : kXcovMaxResponses;
+    const int rc = run_xcov_tile<T>(X, I, P, Y + lo, ldy, mt, S + (int64_t)lo * P, masked, ws, ws_bytes, st, mean, lo == 0 ? ssq_out : nullptr);
+    if (rc != CMTFPLS_OK) return rc;
+  }
+  return CMTFPLS_OK;
 }
 
 template <typename T>
@@ -345,6 +358,7 @@ extern "C" {
 size_t cmtfpls_xcov_workspace_bytes(int64_t I, int64_t P, int M) {
   if (I <= 0 || P <= 0 || M <= 0) return 0;
   const XcovPlan p = plan_xcov(I, P);
+  if (M > kXcovMaxResponses) M = kXcovMaxResponses;       // (more responses: tiles of <= 64 through the same workspace)
   return (size_t)p.row_blocks * M * P * sizeof(double);
 }
 int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
@@ -358,6 +372,7 @@ int cmtfpls_xcov_f64(const double* X, int64_t I, int64_t P, const double* Y, int
 size_t cmtfpls_xcov_ssq_workspace_bytes(int64_t I, int64_t P, int M) {
   if (I <= 0 || P <= 0 || M <= 0) return 0;
   const XcovPlan p = plan_xcov(I, P);
+  if (M > kXcovMaxResponses) M = kXcovMaxResponses;
   return (size_t)p.row_blocks * M * P * sizeof(double) + xcov_ssq_extra(p);
 }
 int cmtfpls_xcov_ssq_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, const double* mean,

@@ -25,8 +25,8 @@ from __future__ import annotations
 
 import contextlib
 import math
-from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from dataclasses import dataclass, field, replace
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -125,35 +125,79 @@ class FitState:
     y_mean: torch.Tensor
     n_iter: List[int]
     n_samples_total: int
+    # which form of every step actually ran (algorithm after fallbacks, reads of X per component, centred or raw, pipelined,
+    # graph replay, ...): `tPLS.fit_report_`
+    report: Dict[str, object] = field(default_factory=dict)
+
+
+@dataclass(frozen=True)
+class EngineOptions:
+    """Which exact form of each step the engine takes WHERE THE SHAPE ALLOWS IT.  Every default is the fastest form; each
+    switch selects the slower equivalent form the tests compare it with.  One object per engine (`NipalsEngine(backend,
+    comm, options)`, `tPLS(..., options=EngineOptions(...))`); what actually ran is written to `FitState.report`
+    (`tPLS.fit_report_`), so a path the shape declined is visible instead of silent."""
+    # a single small float64 block without missing values: the whole fit in ONE launch (cmtfpls_fit_small_f64); a regular
+    # iteration is ~20 launches of pure latency whatever the size, a one-workgroup iteration costs time in proportion to I * P
+    small_fit: bool = True
+    small_fit_elements: int = 1 << 15    # measured (profiles/r03q_small_fit.txt): 2.2x faster at 16000 elements, slower from 65536 on
+    # algorithm="xcov" on blocks without missing values: never deflate X in place (two reads per component instead of a
+    # read and a read + write, FitRun._finish_xcov_nowrite); False keeps the deflating form
+    xcov_nowrite: bool = True
+    # ... and, when X is never written anyway, do not centre it either: the fit runs on the caller's UNCENTRED tensor -- no
+    # centring pass, no private copy -- with two rank-one corrections; False keeps the centred copy
+    xcov_raw: bool = True
+    # the uncentred form works by cancellation: its error grows with max|column mean| / rms spread of the centred data.
+    # Beyond this ratio the fit falls back to the centred private copy (report: raw = False, raw_declined = ratio)
+    xcov_raw_max_offset: float = 1e4
+    # the largest block: score and the contraction with the (block-averaged) score from ONE read of it, the second read per
+    # component replaced by a P x a matrix-vector product; False keeps the two reads
+    xcov_one_read: bool = True
+    # blocks WITH missing values, 2 M <= 64: S = X0^T Y and S2 = X0^T (Y * rowscale) from one matrix-core pass with the
+    # I x 2M right-hand side [Y, Y * rowscale]; False builds them one after the other
+    xcov_pair_build: bool = True
+    # a fit on the uncentred tensor: |X - X_mean|^2 from the read that builds S for the first component instead of a read of
+    # its own (backend.xcov_ssq); False keeps the separate pass
+    xcov_ssq_with_s: bool = True
+    # one block WITH missing values: the deflation happens inside the rebuild of S for the next component (one read + write
+    # of X instead of a read + write and a read, FitRun._finish_xcov_masked_fused); False keeps the two passes
+    xcov_deflate_build: bool = True
+    # the inner loop on S: iteration it + 1 is ENQUEUED before the host has seen iteration it's convergence norm, into a
+    # second set of buffers (FitRun._inner_loop_xcov_pipelined); False waits after every iteration
+    xcov_pipeline: bool = True
+    # sharded direct loop under graph replay: capture the two per-iteration all-reduces INSIDE the iteration's HIP graph (one
+    # replay per iteration instead of three segments and two eager collectives); falls back to the segment-wise form when
+    # the capture fails (report: collectives_in_graph)
+    capture_collectives: bool = False
+    # transform / predict of samples with missing values: rows WITHOUT a missing value keep the one-pass MTTKRP result and
+    # only the affected rows take the masked sequential form; False runs the sequential form on every row of such a batch
+    project_split_rows: bool = True
+
+    def but(self, **changes) -> "EngineOptions":
+        return replace(self, **changes)
+
+
+_DEFAULT_OPTIONS = EngineOptions()
+
+
+def default_options() -> EngineOptions:
+    """The options of an engine constructed without any (the product default: `EngineOptions()`)."""
+    return _DEFAULT_OPTIONS
+
+
+def set_default_options(options: Optional[EngineOptions]) -> EngineOptions:
+    """Replace the process-wide default (None restores `EngineOptions()`); returns the previous one.  The test harness uses it
+    to keep the small float64 fits of the kernel suites on the multi-launch engine (tests/conftest.py)."""
+    global _DEFAULT_OPTIONS
+    old, _DEFAULT_OPTIONS = _DEFAULT_OPTIONS, (options if options is not None else EngineOptions())
+    return old
 
 
 class NipalsEngine:
-    # algorithm="xcov" on blocks without missing values: never deflate X in place (two reads per component instead of a
-    # read and a read + write, see FitRun._finish_xcov_nowrite); False keeps the deflating form (tests compare the two)
-    xcov_nowrite = True
-    # ... and, when X is never written anyway, do not centre it either (round 3): the fit runs on the caller's UNCENTRED tensor --
-    # no centring pass, no private copy -- with two rank-one corrections (FitRun._finish_xcov_nowrite); False keeps the centred copy
-    xcov_raw = True
-    # the largest block: score and the contraction with the (block-averaged) score from ONE read of it, the second read per component
-    # replaced by a P x a matrix-vector product (FitRun._finish_xcov_nowrite); False keeps the two reads (tests compare the two)
-    xcov_one_read = True
-    # blocks WITH missing values, 2 M <= 64: S = X0^T Y and S2 = X0^T (Y * rowscale) from one matrix-core pass with the I x 2M
-    # right-hand side [Y, Y * rowscale] instead of two passes; False builds them one after the other (tests compare the two)
-    xcov_pair_build = True
-    # a fit on the uncentred tensor (xcov_raw): |X - X_mean|^2 from the read that builds S for the first component instead of a
-    # read of its own (backend.xcov_ssq); False keeps the separate pass (tests compare the two)
-    xcov_ssq_with_s = True
-    # one block WITH missing values: the deflation happens inside the rebuild of S for the next component (one read + write of X
-    # instead of a read + write and a read, FitRun._finish_xcov_masked_fused); False keeps the two passes (tests compare the two)
-    xcov_deflate_build = True
-    # the inner loop on S (one NaN-free order-3 block): iteration it + 1 is ENQUEUED before the host has seen iteration it's
-    # convergence norm, into a second set of buffers -- the GPU no longer idles through the status copy, the host's wake-up and
-    # the next launches (FitRun._inner_loop_xcov_pipelined); False waits after every iteration (tests compare the two bit for bit)
-    xcov_pipeline = True
-
-    def __init__(self, backend, comm=None):
+    def __init__(self, backend, comm=None, options: Optional[EngineOptions] = None):
         self.be = backend
         self.comm = comm if comm is not None else _NoComm()
+        self.opt = options if options is not None else default_options()
+        self.last_projection: Dict[str, object] = {}     # which form the last transform / predict took (estimators: projection_report_)
 
     def device_ctx(self):
         """Make the backend's GPU the current HIP device for the duration of a call: the kernels are launched
@@ -202,6 +246,24 @@ class NipalsEngine:
             return False
         blk.ssq0 = float(self.comm.allreduce(out)[1].item())
         return True
+
+    def _offset_ratio(self, blocks: List[BlockState], Xs: List[torch.Tensor]) -> float:
+        """max over blocks of max|column mean| / rms spread of the centred data, the spread estimated from <= 256 rows strided
+        over this rank's shard (an order-of-magnitude guard: a few small elementwise operations, nothing X-sized).  Sharded:
+        every rank must take the same decision, so the sample statistics are all-reduced."""
+        worst = 0.0
+        for blk, X in zip(blocks, Xs):
+            I = X.shape[0]
+            sample = X.view(I, -1)[:: max(1, I // 256)][:256].to(torch.float64) - blk.mean
+            stat = torch.stack([(sample * sample).sum(), torch.tensor(float(sample.numel()), dtype=torch.float64, device=sample.device)])
+            self.comm.allreduce(stat)
+            spread = math.sqrt(float(stat[0].item()) / max(float(stat[1].item()), 1.0))
+            top = float(blk.mean.abs().max().item())
+            if top == 0.0:
+                continue
+            ratio = top / spread if spread > 0.0 else float("inf")
+            worst = ratio if not ratio <= worst else worst          # (a NaN ratio wins: the caller then declines)
+        return worst
 
     def _rank1(self, blk: BlockState, Z: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
                info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None,
@@ -263,21 +325,16 @@ class NipalsEngine:
                 run.finish_component(a)
             return run.result()
 
-    # fits below this many elements of X go through ONE launch when the shape allows it: a regular iteration is ~20
-    # launches of pure latency whatever the size, a one-workgroup iteration costs time in proportion to I * P
-    small_fit_elements = 1 << 15    # measured (profiles/r03q_small_fit.txt): 2.2x faster at 16000 elements, slower from 65536 on
-    small_fit = True
-
     def _fit_small(self, Xs, Y, n_components, tol, max_iter, coupled, verbose, on_preprocessed) -> Optional[FitState]:
         """The whole fit in ONE launch of one workgroup (cmtfpls_fit_small_f64) for a single small float64 block of order
         2 or 3 without missing values, unsharded (BASELINE configs[0]); None when it does not apply -- the caller then
         runs the regular loop.  Same operations in the reference's order (tpls.py:73-120); sums are formed in a different
         order than the multi-launch kernels form them, i.e. results agree to rounding."""
         be = self.be
-        if not (self.small_fit and hasattr(be, "fit_small")) or len(Xs) != 1 or self.comm.sharded or verbose:
+        if not (self.opt.small_fit and hasattr(be, "fit_small")) or len(Xs) != 1 or self.comm.sharded or verbose:
             return None
         X = Xs[0]
-        if X.dtype != torch.float64 or X.dim() not in (2, 3) or X.numel() > self.small_fit_elements or X.shape[0] < 2:
+        if X.dtype != torch.float64 or X.dim() not in (2, 3) or X.numel() > self.opt.small_fit_elements or X.shape[0] < 2:
             return None
         validate_limits([tuple(X.shape)], n_components)
         I = X.shape[0]
@@ -292,8 +349,11 @@ class NipalsEngine:
                          ssq0=float(ssq[0, 0]), dtype=X.dtype, loadings=loadings, r2x=1.0 - ssq[1:, 0] / ssq[0, 0])
         if on_preprocessed is not None:
             on_preprocessed([blk])
+        report = {"form": "small_fit", "algorithm": "direct", "launches": 1, "storage": ["float64"], "shapes": [tuple(X.shape)],
+                  "missing": [False], "sharded": False, "graphs": False,
+                  "note": "the whole fit in one launch of one workgroup (cmtfpls_fit_small_f64); `algorithm` and `graphs` do not apply"}
         return FitState(coupled=coupled, n_components=R, blocks=[blk], T=out["T"], U=out["U"], Q=out["Q"], coef=out["coef"],
-                        r2y=1.0 - ssq[1:, 1] / ssq[0, 1], y_mean=out["y_mean"], n_iter=out["n_iter"], n_samples_total=I)
+                        r2y=1.0 - ssq[1:, 1] / ssq[0, 1], y_mean=out["y_mean"], n_iter=out["n_iter"], n_samples_total=I, report=report)
 
     # ------------------------------------------------------------------------------------
     def project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool = True, mixed: bool = False) -> torch.Tensor:
@@ -305,35 +365,82 @@ class NipalsEngine:
     def project_readonly(self, state: FitState, Xs: List[torch.Tensor]) -> Optional[torch.Tensor]:
         """Scores of new samples from ONE read of every block, the blocks neither copied nor written: the MTTKRP runs on
         the UNCENTRED rows and the centring `X - X_mean` (tpls.py:130,153; cmtf.py:150,187) is applied to its I x R output,
-        (X - 1 mean^T) W = X W - 1 (mean^T W)^T.  None when this form does not apply -- a missing value anywhere in Xs
-        (seen as a NaN in the MTTKRP output), a training column without observations (NaN mean), a shape the MTTKRP does
-        not take and that has no row-in-registers form either -- and the caller then runs `project` on private copies."""
+        (X - 1 mean^T) W = X W - 1 (mean^T W)^T.
+
+        Samples are independent (tpls.py:128-142 works row by row).  A missing value in a sample shows as a NaN in its row of
+        the MTTKRP output; such samples take the reference's masked sequence -- centre, then R times score with the per-row
+        rescale, average the coupled blocks' scores and deflate (missingvals.py:23-38, cmtf.py:143-177) -- while the complete
+        samples of the same batch KEEP their one-pass scores (`EngineOptions.project_split_rows`): in registers from one
+        more read of just those rows (one block, or two coupled blocks in one workgroup), else on compact private copies of
+        those rows through the sequential passes (any number of blocks, any storage types).  A strided sample of the batch
+        is probed first: when most samples are incomplete the MTTKRP attempt would be a wasted read and every row goes
+        through the masked sequence directly.
+
+        None when no read-only form applies (a training column without observations, a shape neither the MTTKRP nor the
+        rows-in-registers kernel takes): the caller then runs `project` on private copies.  `last_projection` records the
+        form taken."""
         with self.device_ctx():
-            if any(bool(torch.isnan(blk.mean).any().item()) for blk in state.blocks):
-                return None
-            flag = torch.zeros(1, dtype=torch.int32, device=self.be.device)
-            scores = self._project_one_pass(state, Xs, False, centred=False, nan_flag=flag)
-            if scores is not None and int(flag.item()) == 0:
-                return scores
-            # a missing value somewhere (or a shape the MTTKRP does not take): the reference's masked sequence -- centre,
-            # then R times score with the per-row rescale, average the coupled blocks' scores and deflate (tpls.py:128-142,
-            # cmtf.py:143-177, missingvals.py:23-38) -- run on every sample in registers, from one read of the uncentred
-            # blocks (one block, or two coupled blocks in one workgroup; more blocks keep the passes)
             be = self.be
-            nb = len(state.blocks)
-            if nb <= 2 and hasattr(be, "project_rows") and all(X.is_contiguous() for X in Xs):
-                I, R = Xs[0].shape[0], state.n_components
-                ops = [self._kr_operands(blk, R) for blk in state.blocks]
-                out = be.empty(I, R)
+            nb, I, R = len(state.blocks), Xs[0].shape[0], state.n_components
+            rep = self.last_projection = {"rows": int(I), "blocks": nb, "form": "sequential passes on private copies", "why": None}
+            if any(bool(torch.isnan(blk.mean).any().item()) for blk in state.blocks):
+                rep["why"] = "a training column without observations (NaN mean)"
+                return None
+            can_rows = (nb <= 2 and hasattr(be, "project_rows") and all(X.is_contiguous() for X in Xs)
+                        and (nb == 1 or hasattr(be, "project_rows2")))
+            ops = None
+
+            def in_registers(out, rows):
+                nonlocal ops
+                ops = ops or [self._kr_operands(blk, R) for blk in state.blocks]
                 if nb == 1:
                     blk = state.blocks[0]
-                    if be.project_rows(Xs[0].view(I, -1), blk.A, blk.B, ops[0][0], ops[0][1], blk.mean, out) is not None:
-                        return out
-                elif hasattr(be, "project_rows2"):
-                    if be.project_rows2([X.view(I, -1) for X in Xs], [b.A for b in state.blocks], [b.B for b in state.blocks],
+                    return be.project_rows(Xs[0].view(I, -1), blk.A, blk.B, ops[0][0], ops[0][1], blk.mean, out, rows=rows)
+                return be.project_rows2([X.view(I, -1) for X in Xs], [b.A for b in state.blocks], [b.B for b in state.blocks],
                                         [o[0].contiguous() for o in ops], [o[1].contiguous() for o in ops],
-                                        [b.mean for b in state.blocks], out) is not None:
+                                        [b.mean for b in state.blocks], out, rows=rows)
+
+            # probe <= 256 samples strided over the batch: mostly incomplete -> skip the MTTKRP attempt (it would be one wasted read)
+            if can_rows and I > 0:
+                step = max(1, I // 256)
+                bad = None
+                for X in Xs:
+                    r = torch.isnan(X.view(I, -1)[::step][:256]).any(dim=1)
+                    bad = r if bad is None else (bad | r)
+                frac = float(bad.double().mean().item())
+                rep["probe_incomplete_fraction"] = frac
+                if frac > 0.5:
+                    out = be.empty(I, R)
+                    if in_registers(out, None) is not None:
+                        rep.update(form="masked sequence, every row in registers (one read)", why="most samples have a missing value")
                         return out
+            flag = torch.zeros(1, dtype=torch.int32, device=be.device)
+            scores = self._project_one_pass(state, Xs, False, centred=False, nan_flag=flag)
+            if scores is not None and int(flag.item()) == 0:
+                rep.update(form="one-pass MTTKRP (one read, nothing written)")
+                return scores
+            rows = None
+            if scores is not None and self.opt.project_split_rows:
+                rows = torch.nonzero(torch.isnan(scores).any(dim=1)).view(-1).contiguous()    # samples with a missing value somewhere
+                rep["incomplete_rows"] = int(rows.numel())
+                if rows.numel() == I:
+                    rows = None
+            if can_rows:
+                out = scores if rows is not None else be.empty(I, R)
+                if in_registers(out, rows) is not None:
+                    rep.update(form=("one-pass MTTKRP for the complete samples + masked sequence in registers for the incomplete ones"
+                                     if rows is not None else "masked sequence, every row in registers (one read)"),
+                               why="missing values in the batch")
+                    return out
+            if rows is not None:
+                # any number of blocks / storage types / trailing extents: compact private copies of the incomplete samples only
+                sub = [X.index_select(0, rows) for X in Xs]
+                scores.index_copy_(0, rows, self._project(state, sub, one_pass=False, mixed=False))
+                rep.update(form="one-pass MTTKRP for the complete samples + sequential passes on copies of the incomplete ones",
+                           why="missing values in the batch; shape outside the rows-in-registers kernel")
+                return scores
+            rep["why"] = ("shape outside the MTTKRP and the rows-in-registers kernel" if scores is None
+                          else "every sample has a missing value; shape outside the rows-in-registers kernel")
             return None
 
     def _project(self, state: FitState, Xs: List[torch.Tensor], one_pass: bool, mixed: bool) -> torch.Tensor:
@@ -479,9 +586,8 @@ class FitRun:
         owned = [True] * len(Xs) if owned is None else list(owned)
         if algorithm not in ("direct", "xcov"):
             raise ValueError("algorithm must be 'direct' or 'xcov'")
-        if algorithm == "xcov" and Y.shape[1] > 64:
-            algorithm = "direct"                                  # S = X^T Y is built for M <= 64 responses
-        self.algorithm = algorithm
+        self.algorithm_requested = self.algorithm = algorithm
+        self.notes: List[str] = []                                # every declined fast form, in words (report["declined"])
         validate_limits([tuple(X.shape) for X in Xs], n_components)   # before the first sweep touches X
         self.eng, self.Xs, self.Y, self.R, self.coupled = eng, Xs, Y, n_components, coupled
         R = n_components
@@ -492,7 +598,7 @@ class FitRun:
         self.n_total = int(round(float(n_tot.item())))
         # algorithm="xcov" on blocks without missing values reads X and never writes it (_finish_xcov_nowrite): then it need not be
         # centred either.  The statistics pass decides: raw = every block NaN-free and every kernel of that path present.
-        want_raw = (allow_raw and algorithm == "xcov" and bool(getattr(eng, "xcov_raw", False)) and bool(getattr(eng, "xcov_nowrite", False))
+        want_raw = (allow_raw and algorithm == "xcov" and eng.opt.xcov_raw and eng.opt.xcov_nowrite
                     and n_components <= 64
                     and all(hasattr(be, f) for f in ("axpy_scalar", "total", "recon_r2", "s_downdate", "deflate_contract_yq", "kr_axpy")))
         if not want_raw:
@@ -500,12 +606,20 @@ class FitRun:
                 if not owned[b]:
                     Xs[b] = Xs[b].clone()                        # the fit centres and deflates in place: never the caller's tensor
         self.blocks = [eng._prepare_block(X, self.n_total, defer_centring=want_raw) for X in Xs]
-        # |X - X_mean|^2 of an uncentred block: from the read that builds S for the first component (backend.xcov_ssq, M <= 64),
+        # |X - X_mean|^2 of an uncentred block: from the read that builds S for the first component (backend.xcov_ssq),
         # else from a read of its own (_ssq_uncentred)
-        self._ssq_with_s = (want_raw and M <= 64 and hasattr(be, "xcov_ssq") and bool(getattr(eng, "xcov_ssq_with_s", True)))
+        self._ssq_with_s = (want_raw and hasattr(be, "xcov_ssq") and eng.opt.xcov_ssq_with_s)
         self._ssq0_dev = {}
-        self.raw = (want_raw and not any(blk.has_miss for blk in self.blocks)
-                    and (self._ssq_with_s or all(eng._ssq_uncentred(blk, X) for blk, X in zip(self.blocks, Xs))))
+        self.raw = want_raw and not any(blk.has_miss for blk in self.blocks)
+        if self.raw:
+            # the uncentred form subtracts mean-sized terms from data-sized results: beyond ~1e4 x the spread it loses digits
+            # the centred copy keeps (error ~ 1e-16 * ratio), so such data is centred after all
+            ratio = eng._offset_ratio(self.blocks, Xs)
+            if not ratio <= eng.opt.xcov_raw_max_offset:
+                self.raw = False
+                self.notes.append(f"uncentred xcov form declined: max|column mean| / spread = {ratio:.3g} > {eng.opt.xcov_raw_max_offset:g}")
+        if self.raw and not self._ssq_with_s:
+            self.raw = all(eng._ssq_uncentred(blk, X) for blk, X in zip(self.blocks, Xs))
         if want_raw and not self.raw:                            # missing values (or no read-only norm): the deflating form after all
             for b, blk in enumerate(self.blocks):
                 if not owned[b]:
@@ -557,6 +671,9 @@ class FitRun:
         self.u_new = be.empty(I)
         self.q = be.empty(M)
         self.n_iter: List[int] = []
+        # the pipelined inner loop on S (report["pipeline"]): iterations accepted, enqueued ahead of the host, enqueued for nothing
+        # (the loop had converged), host round trips the GPU idled through (no speculation), tails redone with the full budget
+        self.pipeline_stats = {"iterations": 0, "ahead": 0, "unused": 0, "waited": 0, "redone": 0}
         self._executed = 0
         self._parity = 0
         self.mixed = False                        # opt-in f32-MFMA form of the S build (f32 storage only)
@@ -584,7 +701,7 @@ class FitRun:
             # masked blocks: Y^T t needs the per-row rescale P / n_obs(i) of miss_mmodedot folded into Y -- a second S, built from
             # Y * rowscale.  2 M <= 64 responses: both come from ONE matrix-core pass over X with [Y, Y * rowscale] as its I x 2M
             # right-hand side (S and S2 are the two halves of one 2M x P result)
-            self._s_pair = 2 * M <= 64 and bool(getattr(eng, "xcov_pair_build", True))
+            self._s_pair = 2 * M <= 64 and eng.opt.xcov_pair_build
             self.S, self.S2, self.S12 = [], [], []
             for blk in self.blocks:
                 if blk.has_miss and self._s_pair:
@@ -619,7 +736,7 @@ class FitRun:
                 self.one = be.empty(1)
                 self.one.fill_(1.0)
                 self.vs = [be.empty(blk.A * blk.B) for blk in self.blocks]
-                self._nowrite = bool(getattr(eng, "xcov_nowrite", False)) and hasattr(be, "kr_axpy") and R <= 64
+                self._nowrite = eng.opt.xcov_nowrite and hasattr(be, "kr_axpy") and R <= 64
                 if self._nowrite:
                     # per component [t^T t, t^T t_b per block] (this rank's rows): |X_{b,a+1}|^2 = |X_{b,a}|^2 - 2 t^T t_b + t^T t
                     # is evaluated on the host in result(), from the all-reduced dot products, instead of measured
@@ -628,7 +745,7 @@ class FitRun:
                     self._G_last = None
                     # the final score and r_a = X_0^T t_a of the LARGEST block come from ONE read of it (_finish_xcov_nowrite),
                     # so its second read per component is a P x a matrix-vector product instead
-                    self._one_read = R > 1 and bool(getattr(eng, "xcov_one_read", False)) and hasattr(be, "score_contract")
+                    self._one_read = R > 1 and eng.opt.xcov_one_read and hasattr(be, "score_contract")
                     if self._one_read:
                         self._fused_b = max(range(len(self.blocks)), key=lambda b: self.blocks[b].A * self.blocks[b].B)
                         P0 = self.blocks[self._fused_b].A * self.blocks[self._fused_b].B
@@ -735,6 +852,7 @@ class FitRun:
     def inner_loop(self, a: int, max_iter: int, tol: float, verbose: int = 0) -> None:
         """The NIPALS iterations of component a (tpls.py:79-107): iterate until |u_old - u| < tol or max_iter."""
         if max_iter > 0 and self._pipeline_ok():
+            self._pipelined = True
             self._inner_loop_xcov_pipelined(a, max_iter, tol, verbose)
             return
         for it in range(max_iter):                                   # tpls.py:79
@@ -751,7 +869,7 @@ class FitRun:
 
     def _pipeline_ok(self) -> bool:
         be = self.eng.be
-        if self.algorithm != "xcov" or self.use_graphs or not bool(getattr(self.eng, "xcov_pipeline", False)):
+        if self.algorithm != "xcov" or self.use_graphs or not self.eng.opt.xcov_pipeline:
             return False
         if self.M > 64 or not all(hasattr(be, f) for f in ("status_snapshot", "status_wait")):
             return False
@@ -785,7 +903,7 @@ class FitRun:
                 "q": [self.qx[0], self.qx[1], be.zeros(M)],
                 "Z": [list(self.Zs), second["Z"]], "wA": [list(self.wA), second["wA"]], "wB": [list(self.wB), second["wB"]],
                 "status": [be.zeros(1 + 2 * nb), be.zeros(1 + 2 * nb)],
-                "plans": {},
+                "plans": {}, "slots": {},                            # (this fit's own pinned status mirrors)
             }
             for st in pp["status"]:
                 st[1::2] = 1.0                                       # (blocks without a rank-1 chain never write their flag)
@@ -815,9 +933,9 @@ class FitRun:
             # iterations of the previous component, whose need the budget remembers -- 4 spare launches (~4 us each when unused)
             # instead of a tail redone in every other component
             plan([n if it > 0 else min(self.sq_max, n + 4) for n in self.sq_budget], first)
-            return be.status_snapshot(pp["status"][it & 1], it & 1)
+            return be.status_snapshot(pp["status"][it & 1], it & 1, slots=pp["slots"])
 
-        stats = self.eng.__dict__.setdefault("pipeline_stats", {"iterations": 0, "ahead": 0, "unused": 0, "waited": 0, "redone": 0})
+        stats = self.pipeline_stats
         it, tok = 0, enqueue(0)
         du_prev = du = None
         while True:
@@ -1067,7 +1185,7 @@ class FitRun:
                 self._finish_xcov_carry(a)
             return
         if (self.algorithm == "xcov" and len(self.blocks) == 1 and self.blocks[0].has_miss and self.S12[0] is not None
-                and a + 1 < self.R and hasattr(be, "xcov_deflate") and bool(getattr(self.eng, "xcov_deflate_build", False))
+                and a + 1 < self.R and hasattr(be, "xcov_deflate") and self.eng.opt.xcov_deflate_build
                 and getattr(self, "_deflate_build_ok", True)):
             if self._finish_xcov_masked_fused(a):
                 return
@@ -1398,5 +1516,63 @@ class FitRun:
             self.r2y[a] = 1.0 - ssq[a, nb] / self.ssqy0                          # tpls.py:118-120
         self._state = FitState(coupled=self.coupled, n_components=self.R, blocks=self.blocks, T=self.T, U=self.U, Q=self.Q,
                                coef=self.coef, r2y=self.r2y, y_mean=self.y_mean, n_iter=self.n_iter,
-                               n_samples_total=self.n_total)
+                               n_samples_total=self.n_total, report=self.build_report())
         return self._state
+
+    def build_report(self) -> Dict[str, object]:
+        """What actually ran (FitState.report, `tPLS.fit_report_`, bench.py `fit.path`): the algorithm, and for every fast form
+        whether it was taken or which condition declined it.  Reads of X are counted per component of the steady state."""
+        eng, comm, nb = self.eng, self.eng.comm, len(self.blocks)
+        rep: Dict[str, object] = {
+            "form": "regular", "algorithm_requested": self.algorithm_requested, "algorithm": self.algorithm,
+            "shapes": [tuple(b.shape) for b in self.blocks], "storage": [str(b.dtype).replace("torch.", "") for b in self.blocks],
+            "missing": [bool(b.has_miss) for b in self.blocks], "responses": self.M,
+            "sharded": bool(comm.sharded), "world": int(comm.world),
+            "graphs": bool(self.use_graphs and self._graphs), "graph_error": self._graph_error,
+            "collectives_in_graph": bool(getattr(self, "_collectives_captured", False)),
+            "backend": getattr(eng.be, "name", type(eng.be).__name__),
+        }
+        if self.algorithm == "direct":
+            rep["y_side"] = "fused into the sweeps" if self._fused else "separate launches"
+            if not self._fused and self.M > 64:
+                self.notes.append("Y side not fused into the sweeps: more than 64 responses")
+            rep["x_passes_per_iteration"] = "2 reads"
+            rep["x_passes_per_component"] = ("1 read + write (deflation fused with the next contraction)" if self._fused
+                                             else "1 read + write (deflation)")
+            rep["x_copy"] = "centred private copy"
+        else:
+            nowrite = bool(getattr(self, "_nowrite", False))
+            one_read = nowrite and bool(getattr(self, "_one_read", False))
+            any_miss = any(b.has_miss for b in self.blocks)
+            rep["x_copy"] = "none: the caller's uncentred tensor is read in place" if self.raw else "centred private copy"
+            rep["raw"] = bool(self.raw)
+            rep["x_written"] = not nowrite
+            rep["s_carried"] = bool(self._s_carry)
+            rep["s_build"] = ("per component (missing values)" if any_miss else "first component only") + \
+                             (f", {(self.M + 63) // 64} response tiles of <= 64" if self.M > 64 else "") + \
+                             (", [Y, Y * rowscale] in one pass" if any(x is not None for x in self.S12) else "")
+            rep["one_read"] = one_read
+            if nowrite:
+                rep["x_passes_per_component"] = ("1 read (largest block); 2 reads (other blocks)" if one_read and nb > 1 else
+                                                 "1 read" if one_read else "2 reads")
+            elif any_miss and nb == 1 and getattr(self, "_deflate_build_ok", True) and self.S12[0] is not None and eng.opt.xcov_deflate_build:
+                rep["x_passes_per_component"] = "1 read + 1 read + write (deflation inside the rebuild of S)"
+            elif any_miss:
+                rep["x_passes_per_component"] = "1 read + write (score + deflation) + S rebuild reads"
+            else:
+                rep["x_passes_per_component"] = "1 read + 1 read + write"
+            rep["pipelined"] = bool(getattr(self, "_pipelined", False))
+            if rep["pipelined"]:
+                rep["pipeline"] = dict(self.pipeline_stats)
+            if not rep["pipelined"] and eng.opt.xcov_pipeline:
+                why = ("graph replay requested" if self.use_graphs else "more than 64 responses" if self.M > 64 else
+                       "a block of order > 3 or a backend without the single-call iteration")
+                self.notes.append("inner loop on S not pipelined: " + why)
+            if self.algorithm_requested == "xcov" and not self.raw and eng.opt.xcov_raw and not any_miss and not any("uncentred" in n for n in self.notes):
+                self.notes.append("uncentred xcov form declined: " + ("more than 64 components" if self.R > 64 else
+                                                                      "f32 matrix precision or a backend without its kernels"))
+            if nowrite and eng.opt.xcov_one_read and self.R > 1 and not one_read:
+                self.notes.append("one read per component declined: the row does not fit the registers of one workgroup "
+                                  "(rows of 2048..16384 f32 / 1024..8192 f64 elements)")
+        rep["declined"] = list(self.notes)
+        return rep

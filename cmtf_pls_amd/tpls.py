@@ -9,7 +9,10 @@ Opt-in extras (defaults reproduce the reference): ``dtype`` (storage type of X o
 ``graphs`` (replay each iteration as a HIP graph), ``matrix_precision`` ("f64" | "f32": the opt-in
 f32-MFMA form of the two matrix-core kernels), ``copy_X`` (False: fit a device-resident X in place),
 ``device``, ``comm`` (sample-mode sharding: each
-rank passes its own rows), ``n_iter_`` (inner iterations executed per component) and
+rank passes its own rows), ``options`` (an ``EngineOptions``: which exact form of each step to take where the shape
+allows it), ``n_iter_`` (inner iterations executed per component), ``fit_report_`` / ``projection_report_`` (which
+forms actually ran: algorithm after fallbacks, passes over X per component, centred copy or the caller's tensor,
+pipelined, graph replay, projection form; every declined fast form in words) and
 ``original_X / original_Y`` (which the reference's validate.get_q2y reads, validate.py:18-21).
 """
 from __future__ import annotations
@@ -21,7 +24,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .engine import Comm, NipalsEngine
+from .engine import Comm, EngineOptions, NipalsEngine
 
 
 def _as_torch_dtype(dtype, like) -> torch.dtype:
@@ -75,9 +78,11 @@ def _project_blocks(eng: NipalsEngine, state, Xs, dtypes, mixed: bool) -> torch.
 
 class _EstimatorBase(Mapping):
     def __init__(self, n_components: int, dtype=None, device=None, comm: Optional[Comm] = None, backend=None,
-                 algorithm: str = "direct", graphs: bool = False, matrix_precision: str = "f64", copy_X: bool = True):
+                 algorithm: str = "direct", graphs: bool = False, matrix_precision: str = "f64", copy_X: bool = True,
+                 options: Optional[EngineOptions] = None):
         super().__init__()
         self.n_components = n_components
+        self._options = options                   # None: the process default (engine.default_options())
         self._algorithm = algorithm
         self._graphs = graphs                     # replay each iteration's launch sequence as a HIP graph
         if matrix_precision not in ("f64", "f32"):
@@ -96,7 +101,7 @@ class _EstimatorBase(Mapping):
                 from .backend import HipBackend   # raises if the GPU or libcmtfpls.so is missing
 
                 self._backend = HipBackend(self._device)
-            self._engine = NipalsEngine(self._backend, self._comm)
+            self._engine = NipalsEngine(self._backend, self._comm, self._options)
         return self._engine
 
     def __iter__(self):
@@ -106,6 +111,17 @@ class _EstimatorBase(Mapping):
 
     def __len__(self):
         return 3
+
+    @property
+    def fit_report_(self) -> dict:
+        """Which form of every step the last fit took (engine.FitRun.build_report)."""
+        return dict(self._state.report)
+
+    @property
+    def projection_report_(self) -> dict:
+        """Which form the last transform / predict took: one-pass MTTKRP, rows with missing values in registers, or the
+        sequential passes -- and why."""
+        return dict(self._get_engine().last_projection)
 
     def copy(self):
         return copy(self)

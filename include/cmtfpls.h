@@ -118,7 +118,8 @@ int cmtfpls_kron_f64(const double* a, int na, const double* b, int nb, double* o
  * f64 matrix cores (v_mfma_f64_16x16x4_f64), one read of X.  Inside one component u = Y q, hence
  * np.einsum(X, u) = sum_m q_m S[m] (tpls.py:83) and Y.T @ t = S_(0) kron(wA, wB) (tpls.py:100): the
  * inner loop of tpls.py:79-107 can then run on S alone with mode0_contract_f64 / rank1 / score_f64
- * applied to S.  masked != 0: NaN entries of X contribute 0.  M <= 64.
+ * applied to S.  masked != 0: NaN entries of X contribute 0.  Any M (the reference has no limit, tpls.py:100-102): one pass
+ * over X per 64 responses, all through the same workspace (sized for min(M, 64) responses).
  * quadform: out[0] = (q - q_old)^T G (q - q_old) = |Y q - Y q_old|^2 for G = Y^T Y (tpls.py:103). */
 size_t cmtfpls_xcov_workspace_bytes(int64_t I, int64_t P, int M);
 int cmtfpls_xcov_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S,
@@ -334,6 +335,21 @@ int cmtfpls_project_rows2_f32(const float* X0, int A0, int B0, const double* WA0
 int cmtfpls_project_rows2_f64(const double* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
                               const double* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,
                               int64_t I, int R, double* scores, int ld, void* stream);
+/* project_rows_idx / project_rows2_idx (round 4): the same sequence for the n_rows samples listed in `rows` (device array of
+ * sample indices into X and scores) only.  The samples of a batch are independent (tpls.py:128-142 works row by row), so a
+ * sample WITHOUT a missing value keeps the score of the one-pass form (cmtfpls_mttkrp_* + cmtfpls_unit_upper_solve_rows_f64)
+ * and only the samples with one take the masked sequence: a batch with a few incomplete samples no longer pays the
+ * arithmetic-bound sequence for all of them.  Shape limits as above; n_rows = 0 is a no-op. */
+int cmtfpls_project_rows_idx_f32(const float* X, const int64_t* rows, int64_t n_rows, int A, int B, int R, const double* WA,
+                                 const double* WB, const double* mean, double* scores, int ld, void* stream);
+int cmtfpls_project_rows_idx_f64(const double* X, const int64_t* rows, int64_t n_rows, int A, int B, int R, const double* WA,
+                                 const double* WB, const double* mean, double* scores, int ld, void* stream);
+int cmtfpls_project_rows2_idx_f32(const float* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
+                                  const float* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,
+                                  const int64_t* rows, int64_t n_rows, int R, double* scores, int ld, void* stream);
+int cmtfpls_project_rows2_idx_f64(const double* X0, int A0, int B0, const double* WA0, const double* WB0, const double* mean0,
+                                  const double* X1, int A1, int B1, const double* WA1, const double* WB1, const double* mean1,
+                                  const int64_t* rows, int64_t n_rows, int R, double* scores, int ld, void* stream);
 
 /* ---- collectives of the sharded loop for callers that drive this C ABI directly -----------------------
  * In-place all-reduce(sum) of a device buffer over the caller's RCCL communicator (an ncclComm_t passed as void*), on

@@ -29,12 +29,21 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _regular_engine_unless_asked(request):
-    """The one-launch small-fit path (NipalsEngine._fit_small, round 3) would swallow every small float64 fit of the
-    suites written to exercise the multi-launch kernels; they keep the regular engine.  Tests marked `small_fit` (and
-    the port of the reference's own suite, which should see the product's default behaviour) leave the default on."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    """Harness default of `EngineOptions`: the one-launch small-fit path (NipalsEngine._fit_small) would swallow every small
+    float64 fit of the suites written to exercise the multi-launch kernels (it ignores `algorithm` and `graphs`), so engines
+    constructed WITHOUT explicit options keep the regular engine here.  Tests marked `small_fit` -- the port of the
+    reference's own suite, the configs[0] golden tests in both modes (`small_fit_mode`) -- see the product default; tests of
+    one switch construct their own `EngineOptions(...)` and pass it to the estimator."""
+    from cmtf_pls_amd.engine import EngineOptions, set_default_options
     keep = request.node.get_closest_marker("small_fit") is not None
-    old = NipalsEngine.small_fit
-    NipalsEngine.small_fit = old if keep else False
+    old = set_default_options(EngineOptions() if keep else EngineOptions(small_fit=False))
     yield
-    NipalsEngine.small_fit = old
+    set_default_options(old)
+
+
+@pytest.fixture(params=["one_launch", "regular"])
+def small_fit_mode(request):
+    """Estimator-level tests that must hold on BOTH paths a small float64 fit can take: the product default (the whole
+    fit in one launch) and the regular multi-launch engine.  Yields the EngineOptions to pass as `options=`."""
+    from cmtf_pls_amd.engine import EngineOptions
+    return EngineOptions(small_fit=(request.param == "one_launch"))

@@ -133,8 +133,6 @@ class NumpyBackend:
         return torch.tensor([float(((xhat - x)[ok] ** 2).sum()), float((x[ok] ** 2).sum())], dtype=torch.float64)
 
     def xcov_ssq(self, X2, Y, mean, out):
-        if Y.shape[1] > 64:
-            return None
         x = _np(X2).astype(np.float64)
         out.copy_(torch.from_numpy(_np(Y).T @ x))
         return out, torch.tensor([float(((x - _np(mean)) ** 2).sum())], dtype=torch.float64)
@@ -146,7 +144,7 @@ class NumpyBackend:
         self.xcov(X2, Y, True, out=out)
         return ssq
 
-    def status_snapshot(self, status, slot):
+    def status_snapshot(self, status, slot, slots=None):
         return status.clone().numpy()
 
     def status_wait(self, token):

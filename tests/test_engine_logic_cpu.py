@@ -11,6 +11,7 @@ import torch
 
 import oracle as O
 from cmtf_pls_amd import ctPLS, tPLS
+from cmtf_pls_amd.engine import default_options
 from numpy_backend import NumpyBackend
 
 
@@ -201,7 +202,7 @@ def test_xcov_without_writing_x_equals_the_deflating_form(case, monkeypatch):
     carried implicitly.  Same scores, loadings, coefficients, R2X (from the norm recurrence) and iteration counts as the
     form that deflates in place (NipalsEngine.xcov_nowrite = False) and as the direct loop; the engine's copy of X ends
     the fit exactly as it was centred."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     rng = np.random.default_rng(77)
     R = 4
     if case == "coupled":
@@ -218,12 +219,12 @@ def test_xcov_without_writing_x_equals_the_deflating_form(case, monkeypatch):
     Y = rng.random((30, 3))
 
     def fit(nowrite, algorithm="xcov"):
-        monkeypatch.setattr(NipalsEngine, "xcov_nowrite", nowrite)
+        opt["xcov_nowrite"] = nowrite
         if len(Xs) > 1:
-            m = ctPLS(R, backend=NumpyBackend(), algorithm=algorithm)
+            m = ctPLS(R, backend=NumpyBackend(), algorithm=algorithm, options=default_options().but(**opt))
             m.fit(Xs, Y)
             return m, m.factor_T, m.R2Xs, [f for fs in m.Xs_factors for f in fs[1:]]
-        m = tPLS(R, backend=NumpyBackend(), algorithm=algorithm)
+        m = tPLS(R, backend=NumpyBackend(), algorithm=algorithm, options=default_options().but(**opt))
         m.fit(Xs[0], Y)
         return m, m.X_factors[0], [m.R2X], m.X_factors[1:]
 
@@ -245,11 +246,11 @@ def test_xcov_without_writing_x_equals_the_deflating_form(case, monkeypatch):
     if len(Xs) == 1:                                   # (a coupled fit's R2Xs need not increase: tests/test_cmtf.py:27,39)
         assert np.all(np.diff(r2b[0]) >= -1e-9) and r2b[0][-1] <= 1 + 1e-9        # the norm recurrence stays monotone and <= 1
     # the never-write fit leaves its working copy as centred (with `xcov_raw` it would not even be centred: the next test)
-    monkeypatch.setattr(NipalsEngine, "xcov_nowrite", True)
-    monkeypatch.setattr(NipalsEngine, "xcov_raw", False)
+    opt["xcov_nowrite"] = True
+    opt["xcov_raw"] = False
     import torch
     Xd = torch.from_numpy(Xs[0].copy())
-    m = (ctPLS if len(Xs) > 1 else tPLS)(R, backend=NumpyBackend(), algorithm="xcov", copy_X=False)
+    m = (ctPLS if len(Xs) > 1 else tPLS)(R, backend=NumpyBackend(), algorithm="xcov", copy_X=False, options=default_options().but(**opt))
     if len(Xs) > 1:
         m.fit([Xd] + Xs[1:], Y)
     else:
@@ -263,7 +264,7 @@ def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
     X_0^T yhat = sum_j b_j r_j from the kept r_j instead of a second read (FitRun._finish_xcov_nowrite); with coupled blocks the
     kernel is handed the other blocks' scores and contracts with the block average.  Same fit as with the two reads
     (NipalsEngine.xcov_one_read = False); "declined": the backend refuses the shape and the engine makes the two passes."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     rng = np.random.default_rng(78)
     R = 4
     shape = {"tpls3": (30, 7, 6), "tpls4": (30, 6, 5, 4), "matrix": (30, 24), "declined": (30, 7, 5),
@@ -288,8 +289,8 @@ def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
     monkeypatch.setattr(NumpyBackend, "score_contract", counted)
 
     def fit(one_read):
-        monkeypatch.setattr(NipalsEngine, "xcov_one_read", one_read)
-        m = (ctPLS if len(blocks) > 1 else tPLS)(R, backend=NumpyBackend(), algorithm="xcov")
+        opt["xcov_one_read"] = one_read
+        m = (ctPLS if len(blocks) > 1 else tPLS)(R, backend=NumpyBackend(), algorithm="xcov", options=default_options().but(**opt))
         m.fit(blocks if len(blocks) > 1 else x, Y)
         return m
 
@@ -323,7 +324,7 @@ def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
 def test_xcov_on_the_uncentred_tensor_equals_the_centred_form_cpu(case, monkeypatch):
     """NipalsEngine.xcov_raw through the NumPy backend: the fit reads the caller's uncentred blocks (never written, never centred)
     and applies the centring algebraically; |X - X_mean|^2 comes out of the S-build read (xcov_ssq).  Same fit as on centred copies."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     import torch
     rng = np.random.default_rng(5)
     x, y, cp = O.import_synthetic((40, 6, 5), 3, 3, error=0.2, seed=8)
@@ -341,9 +342,9 @@ def test_xcov_on_the_uncentred_tensor_equals_the_centred_form_cpu(case, monkeypa
         monkeypatch.setattr(NumpyBackend, name, counted)
 
     def fit(raw):
-        monkeypatch.setattr(NipalsEngine, "xcov_raw", raw)
+        opt["xcov_raw"] = raw
         held = [torch.from_numpy(b.copy()) for b in blocks]
-        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov", copy_X=False)
+        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov", copy_X=False, options=default_options().but(**opt))
         m.fit(held if coupled else held[0], y)
         return m, held
 
@@ -384,13 +385,13 @@ def test_xcov_pipelined_inner_loop_is_bit_identical_to_the_waiting_loop(backend,
     """FitRun._inner_loop_xcov_pipelined enqueues iteration it + 1 before the host has seen iteration it's norm (second buffer
     set, three q buffers): same kernels on the same data in the same order as the loop that waits after every iteration --
     identical bits, identical iteration counts, also when max_iter cuts the loop and when tails have to be redone."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     x, y, _ = O.import_synthetic((60, 9, 7), 4, 3, error=0.3, seed=11)
 
     def fit(pipeline):
-        monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
+        opt["xcov_pipeline"] = pipeline
         backend.retries = 0
-        m = tPLS(4, backend=backend(), algorithm="xcov")
+        m = tPLS(4, backend=backend(), algorithm="xcov", options=default_options().but(**opt))
         m.fit(x, y, max_iter=max_iter)
         return m, backend.retries
 
@@ -412,7 +413,7 @@ def test_xcov_pipelined_inner_loop_is_bit_identical_to_the_waiting_loop(backend,
 def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(case, monkeypatch):
     """The pipelined inner loop through the several-blocks entry (backend.xcov_blocks_plan: coupled blocks, blocks with missing
     values, matrix blocks): same iteration counts and factors as the loop that waits after every iteration, and as the oracle."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     rng = np.random.default_rng(21)
     x, y, cp = O.import_synthetic((50, 8, 6), 3, 3, error=0.2, seed=5)
     xm = cp.factors[0] @ rng.normal(size=(11, 3)).T + 0.2 * rng.normal(size=(50, 11))
@@ -431,8 +432,8 @@ def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(case, monkeypat
     monkeypatch.setattr(NumpyBackend, "xcov_blocks_plan", counted)
 
     def fit(pipeline):
-        monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
-        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov")
+        opt["xcov_pipeline"] = pipeline
+        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov", options=default_options().but(**opt))
         m.fit(blocks if coupled else blocks[0], y)
         return m
 
@@ -454,7 +455,7 @@ def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(case, monkeypat
 def test_xcov_masked_blocks_build_both_cross_covariances_in_one_pass(coupled, monkeypatch):
     """A block with missing values needs S = X0^T Y (contraction) and S2 = X0^T (Y * rowscale) (the masked score's P / n_obs(i)
     folded into Y): with 2 M <= 64 both are the halves of ONE xcov pass over X with [Y, Y * rowscale]; same fit as two passes."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     rng = np.random.default_rng(9)
     x = rng.random((40, 6, 5))
     x[rng.random(x.shape) < 0.2] = np.nan
@@ -470,9 +471,9 @@ def test_xcov_masked_blocks_build_both_cross_covariances_in_one_pass(coupled, mo
     monkeypatch.setattr(NumpyBackend, "xcov", counted)
 
     def fit(pair):
-        monkeypatch.setattr(NipalsEngine, "xcov_pair_build", pair)
+        opt["xcov_pair_build"] = pair
         passes["n"], passes["widths"] = 0, []
-        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov")
+        m = (ctPLS if coupled else tPLS)(3, backend=NumpyBackend(), algorithm="xcov", options=default_options().but(**opt))
         m.fit(blocks if coupled else x, Y)
         return m, passes["n"], set(passes["widths"])
 

@@ -51,12 +51,15 @@ def check_against_oracle(m, fit, rtol, block=0, exact_iters=True):
         assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
 
 
+@pytest.mark.small_fit
 @pytest.mark.parametrize("err", [0.0, 0.1])
-def test_tpls_cfg1_f64(api, golden_dir, err):
-    """BASELINE.json configs[0]: synthetic (200,10,8), M=4, R=3."""
+def test_tpls_cfg1_f64(api, golden_dir, err, small_fit_mode):
+    """BASELINE.json configs[0]: synthetic (200,10,8), M=4, R=3 -- on BOTH paths such a fit can take: the product default (the
+    whole fit in one launch, cmtfpls_fit_small_f64) and the regular multi-launch engine."""
     x, y, _ = O.import_synthetic((200, 10, 8), 4, 3, error=err)
-    m = api.tPLS(3)
+    m = api.tPLS(3, options=small_fit_mode)
     m.fit(x, y)
+    assert m.fit_report_["form"] == ("small_fit" if small_fit_mode.small_fit else "regular")
     fit = O.fit_tpls(x, y, 3)
     check_against_oracle(m, fit, 1e-7)
     assert_allclose(m.R2X, fit.r2x[0], rtol=1e-8, atol=1e-9)

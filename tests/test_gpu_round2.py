@@ -7,6 +7,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from cmtf_pls_amd.engine import default_options
 import torch
 
 import oracle as O
@@ -175,8 +177,8 @@ def test_kr_axpy_kernel(be):
 def test_xcov_without_writing_x_on_gpu(dtype, case, monkeypatch):
     """algorithm="xcov" without deflating X (two reads per component, FitRun._finish_xcov_nowrite) against the form that
     deflates in place and against the oracle; the device tensor handed over with copy_X=False ends the fit as centred."""
+    opt = {}                                              # EngineOptions fields this test overrides
     from cmtf_pls_amd import ctPLS, tPLS
-    from cmtf_pls_amd.engine import NipalsEngine
     td = getattr(torch, dtype)
     R = 4
     if case == "order4":
@@ -191,15 +193,15 @@ def test_xcov_without_writing_x_on_gpu(dtype, case, monkeypatch):
     fit = O.fit_ctpls(Xs, y, R) if case == "coupled" else O.fit_tpls(Xs[0], y, R)
 
     # (this test is about writing X or not: the round-3 form that does not even CENTRE it has its own, tests/test_gpu_round3.py)
-    monkeypatch.setattr(NipalsEngine, "xcov_raw", False)
+    opt["xcov_raw"] = False
 
     def run(nowrite, keep=None):
-        monkeypatch.setattr(NipalsEngine, "xcov_nowrite", nowrite)
+        opt["xcov_nowrite"] = nowrite
         if case == "coupled":
-            m = ctPLS(R, dtype=dtype, algorithm="xcov", copy_X=keep is None)
+            m = ctPLS(R, dtype=dtype, algorithm="xcov", copy_X=keep is None, options=default_options().but(**opt))
             m.fit(Xs if keep is None else keep, y)
             return m, m.factor_T, m.R2Xs[0]
-        m = tPLS(R, dtype=dtype, algorithm="xcov", copy_X=keep is None)
+        m = tPLS(R, dtype=dtype, algorithm="xcov", copy_X=keep is None, options=default_options().but(**opt))
         m.fit(Xs[0] if keep is None else keep[0], y)
         return m, m.X_factors[0], m.R2X
 

@@ -3,6 +3,8 @@ regression beyond 64 components, rank-deficient score matrices (ADVICE low), the
 low), float64 X_reconstructed (ADVICE low)."""
 import numpy as np
 import pytest
+
+from cmtf_pls_amd.engine import default_options
 import torch
 from numpy.testing import assert_allclose
 
@@ -254,14 +256,14 @@ def test_coupled_nan_transform_from_one_read(api, monkeypatch, dtype):
 def test_small_fit_in_one_launch_equals_the_regular_engine(api, monkeypatch, shape, M, R):
     """BASELINE configs[0] and neighbours: tPLS.fit of a small float64 problem is ONE kernel launch (cmtfpls_fit_small_f64);
     same iteration counts, factors equal to the multi-launch engine to 1e-12 and to the oracle."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     x, y, _ = O.import_synthetic(shape, M, min(R, 4), error=0.1, seed=7)
     calls = _count_calls(monkeypatch, ["fit_small", "colstats", "mode0_contract", "mode0_contract_yq", "rank1"])
-    one = api.tPLS(R)
+    one = api.tPLS(R, options=default_options().but(**opt))
     one.fit(x, y)
     assert calls["fit_small"] == 1 and calls["colstats"] == calls["mode0_contract"] == calls["mode0_contract_yq"] == calls["rank1"] == 0
-    monkeypatch.setattr(NipalsEngine, "small_fit", False)
-    reg = api.tPLS(R)
+    opt["small_fit"] = False
+    reg = api.tPLS(R, options=default_options().but(**opt))
     reg.fit(x, y)
     assert calls["fit_small"] == 1 and calls["colstats"] > 0
     assert one.n_iter_ == reg.n_iter_
@@ -347,7 +349,7 @@ def test_three_coupled_blocks_with_an_empty_row_keep_the_references_nan_semantic
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("case", ["tensor", "coupled", "order4", "matrix"])
 def test_xcov_on_the_uncentred_tensor_equals_the_centred_form(api, monkeypatch, case, dtype):
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     rng = np.random.default_rng(31)
     shape = {"tensor": (300, 24, 32), "coupled": (300, 24, 32), "order4": (120, 6, 5, 8), "matrix": (200, 96)}[case]
     x, y, cp = O.import_synthetic(shape, 5, 4, error=0.1, seed=13)
@@ -357,14 +359,14 @@ def test_xcov_on_the_uncentred_tensor_equals_the_centred_form(api, monkeypatch, 
         blocks.append(cp.factors[0] @ rng.normal(size=(64, 4)).T + 0.1 * rng.normal(size=(300, 64)) - 3.0)
     if dtype == "float32":
         blocks, y = [_f32(b) for b in blocks], _f32(y)
-    make = (lambda: api.ctPLS(4, dtype=dtype, algorithm="xcov")) if case == "coupled" else (lambda: api.tPLS(4, dtype=dtype, algorithm="xcov"))
+    make = (lambda: api.ctPLS(4, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))) if case == "coupled" else (lambda: api.tPLS(4, dtype=dtype, algorithm="xcov", options=default_options().but(**opt)))
     arg = blocks if case == "coupled" else blocks[0]
     calls = _count_calls(monkeypatch, ["center", "axpy_scalar", "deflate", "score_deflate", "deflate_contract_yq"])
     raw = make()
     raw.fit(arg, y)
     assert calls["center"] == 1 and calls["axpy_scalar"] > 0                 # (the one centring call is Y's)
     assert calls["deflate"] == calls["score_deflate"] == calls["deflate_contract_yq"] == 0
-    monkeypatch.setattr(NipalsEngine, "xcov_raw", False)
+    opt["xcov_raw"] = False
     cen = make()
     cen.fit(arg, y)
     assert calls["center"] == 1 + 1 + len(blocks)
@@ -469,13 +471,13 @@ def test_xcov_fit_with_one_read_per_component_equals_the_two_reads(api, monkeypa
     """tPLS(algorithm="xcov") on one block reads X once per component (plus the two reads that build S and the norm): the second
     read is replaced by X_0^T yhat = sum_j b_j r_j with r_j = X_0^T t_j kept from the pass that formed t_j.  Same iterations, same
     factors as with the two reads (NipalsEngine.xcov_one_read = False) and as the oracle."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     R = 5
     x, y, _ = O.import_synthetic(shape, 6, 4, error=0.1, seed=17)
     x = x + 4.0
     if dtype == "float32":
         x, y = _f32(x), _f32(y)
-    monkeypatch.setattr(NipalsEngine, "xcov_raw", raw)
+    opt["xcov_raw"] = raw
     from cmtf_pls_amd.backend import HipBackend
     calls = _count_calls(monkeypatch, ["score_contract"])
     calls["reads"] = 0                                             # passes over the I-row tensor (the inner loop makes the same calls on S)
@@ -486,11 +488,11 @@ def test_xcov_fit_with_one_read_per_component_equals_the_two_reads(api, monkeypa
             calls["reads"] += X2.shape[0] == shape[0]
             return __orig(self, X2, *a, **k)
         monkeypatch.setattr(HipBackend, name, counted)
-    one = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    one = api.tPLS(R, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))
     one.fit(x, y)
     assert calls["score_contract"] == R - 1 and calls["reads"] == 1           # the last component's score
-    monkeypatch.setattr(NipalsEngine, "xcov_one_read", False)
-    two = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    opt["xcov_one_read"] = False
+    two = api.tPLS(R, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))
     two.fit(x, y)
     assert calls["score_contract"] == R - 1 and calls["reads"] == 1 + R + (R - 1)
     assert one.n_iter_ == two.n_iter_
@@ -511,8 +513,8 @@ def test_xcov_coupled_fit_reads_the_largest_block_once_per_component(api, monkey
     """ctPLS(algorithm="xcov"): the deflation uses the block-AVERAGED score, so the pass over the largest block is handed the other
     blocks' scores (read first) and contracts with the average; the small blocks keep their two reads.  Same fit as with two
     reads everywhere, and as the oracle."""
+    opt = {}                                              # EngineOptions fields this test overrides
     from cmtf_pls_amd.backend import HipBackend
-    from cmtf_pls_amd.engine import NipalsEngine
     R, I = 5, 300
     rng = np.random.default_rng(5)
     x, y, cp = O.import_synthetic((I, 64, 64), 6, 4, error=0.1, seed=19)
@@ -521,7 +523,7 @@ def test_xcov_coupled_fit_reads_the_largest_block_once_per_component(api, monkey
         blocks.append(np.einsum("ir,jr,kr->ijk", cp.factors[0], rng.normal(size=(6, 4)), rng.normal(size=(8, 4))) + 0.1 * rng.normal(size=(I, 6, 8)))
     blocks = [_f32(b) for b in blocks]
     y = _f32(y)
-    monkeypatch.setattr(NipalsEngine, "xcov_raw", raw)
+    opt["xcov_raw"] = raw
     seen = []
     orig = HipBackend.score_contract
 
@@ -530,11 +532,11 @@ def test_xcov_coupled_fit_reads_the_largest_block_once_per_component(api, monkey
         seen.append((X2.shape[1], out is not None, k.get("alpha")))
         return out
     monkeypatch.setattr(HipBackend, "score_contract", counted)
-    one = api.ctPLS(R, dtype="float32", algorithm="xcov")
+    one = api.ctPLS(R, dtype="float32", algorithm="xcov", options=default_options().but(**opt))
     one.fit(blocks, y)
     assert seen == [(64 * 64, True, 1.0 / len(blocks))] * (R - 1)
-    monkeypatch.setattr(NipalsEngine, "xcov_one_read", False)
-    two = api.ctPLS(R, dtype="float32", algorithm="xcov")
+    opt["xcov_one_read"] = False
+    two = api.ctPLS(R, dtype="float32", algorithm="xcov", options=default_options().but(**opt))
     two.fit(blocks, y)
     assert len(seen) == R - 1 and one.n_iter_ == two.n_iter_
     assert _normwise(one.factor_T, two.factor_T) <= 1e-10
@@ -553,8 +555,8 @@ def test_xcov_coupled_fit_reads_the_largest_block_once_per_component(api, monkey
 def test_xcov_masked_fit_builds_both_cross_covariances_in_one_pass(api, monkeypatch, M):
     """Blocks with missing values: S = X0^T Y and S2 = X0^T (Y * rowscale) are the halves of ONE matrix-core pass with the I x 2M
     right-hand side [Y, Y * rowscale] when 2 M <= 64 (M = 40: two passes as before).  Same fit as with two passes; equals the oracle."""
+    opt = {}                                              # EngineOptions fields this test overrides
     from cmtf_pls_amd.backend import HipBackend
-    from cmtf_pls_amd.engine import NipalsEngine
     R = 4
     x, y, _ = O.import_synthetic((300, 32, 64), M, 4, error=0.1, seed=23)
     rng = np.random.default_rng(2)
@@ -567,13 +569,13 @@ def test_xcov_masked_fit_builds_both_cross_covariances_in_one_pass(api, monkeypa
         widths.append(Yd.shape[1])
         return orig(self, X2, Yd, *a, **k)
     monkeypatch.setattr(HipBackend, "xcov", counted)
-    monkeypatch.setattr(NipalsEngine, "xcov_deflate_build", False)          # (that form rebuilds S inside the deflation: its own test)
-    one = api.tPLS(R, dtype="float32", algorithm="xcov")
+    opt["xcov_deflate_build"] = False          # (that form rebuilds S inside the deflation: its own test)
+    one = api.tPLS(R, dtype="float32", algorithm="xcov", options=default_options().but(**opt))
     one.fit(x, y)
     assert widths == ([2 * M] * R if 2 * M <= 64 else [M] * (2 * R))
-    monkeypatch.setattr(NipalsEngine, "xcov_pair_build", False)
+    opt["xcov_pair_build"] = False
     widths.clear()
-    two = api.tPLS(R, dtype="float32", algorithm="xcov")
+    two = api.tPLS(R, dtype="float32", algorithm="xcov", options=default_options().but(**opt))
     two.fit(x, y)
     assert widths == [M] * (2 * R)
     assert one.n_iter_ == two.n_iter_
@@ -590,15 +592,15 @@ def test_xcov_pipelined_inner_loop_is_bit_identical_to_the_waiting_loop(api, mon
     """The inner loop on S with iteration it + 1 enqueued before the host has seen iteration it's convergence norm (second buffer
     set; FitRun._inner_loop_xcov_pipelined): the same kernels on the same data in the same order as the loop that waits after
     every iteration -- identical bits and iteration counts; `max_iter` cutting the loop included."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     x, y, _ = O.import_synthetic(shape, 6, 5, error=0.2, seed=29)
     if dtype == "float32":
         x, y = _f32(x), _f32(y)
     for max_iter in (100, 3):
         fits = []
         for pipeline in (False, True):
-            monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
-            m = api.tPLS(5, dtype=dtype, algorithm="xcov")
+            opt["xcov_pipeline"] = pipeline
+            m = api.tPLS(5, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))
             m.fit(x, y, max_iter=max_iter)
             fits.append(m)
         wait, pipe = fits
@@ -614,8 +616,8 @@ def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(api, monkeypatc
     """Coupled blocks, blocks with missing values and matrix blocks run the pipelined inner loop through ONE host call per iteration
     (cmtfpls_xcov_iterate_blocks_f64): same iteration counts and factors (to rounding: the q update is one kernel there, two in the
     waiting loop) as the loop that waits after every iteration; equals the oracle."""
+    opt = {}                                              # EngineOptions fields this test overrides
     from cmtf_pls_amd.backend import HipBackend
-    from cmtf_pls_amd.engine import NipalsEngine
     rng = np.random.default_rng(33)
     x, y, cp = O.import_synthetic((300, 32, 64), 6, 4, error=0.2, seed=31)
     xm = cp.factors[0] @ rng.normal(size=(96, 4)).T + 0.2 * rng.normal(size=(300, 96))
@@ -627,8 +629,8 @@ def test_xcov_pipelined_inner_loop_for_coupled_and_masked_blocks(api, monkeypatc
     plans = _count_calls(monkeypatch, ["xcov_blocks_plan"])
     fits = []
     for pipeline in (False, True):
-        monkeypatch.setattr(NipalsEngine, "xcov_pipeline", pipeline)
-        m = (api.ctPLS if coupled else api.tPLS)(4, dtype="float32", algorithm="xcov")
+        opt["xcov_pipeline"] = pipeline
+        m = (api.ctPLS if coupled else api.tPLS)(4, dtype="float32", algorithm="xcov", options=default_options().but(**opt))
         m.fit(blocks if coupled else blocks[0], y)
         fits.append(m)
         assert (plans["xcov_blocks_plan"] > 0) == pipeline
@@ -665,17 +667,17 @@ def test_xcov_ssq_kernel_gives_s_and_the_centred_norm_from_one_read(be, dtype, I
 def test_xcov_raw_fit_takes_the_norm_from_the_s_build(api, monkeypatch, dtype, shape):
     """A fit on the uncentred tensor needs |X - X_mean|^2 for R2X: from the read that builds S (cmtfpls_xcov_ssq_*) instead of
     a read of its own (cmtfpls_recon_r2_* against a zero reconstruction).  Same R2X."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     x, y, _ = O.import_synthetic(shape, 5, 4, error=0.1, seed=41)
     x = x + 6.0
     if dtype == "float32":
         x, y = _f32(x), _f32(y)
     calls = _count_calls(monkeypatch, ["recon_r2", "xcov_ssq", "xcov"])
-    one = api.tPLS(4, dtype=dtype, algorithm="xcov")
+    one = api.tPLS(4, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))
     one.fit(x, y)
     assert (calls["recon_r2"], calls["xcov_ssq"], calls["xcov"]) == (0, 1, 0)
-    monkeypatch.setattr(NipalsEngine, "xcov_ssq_with_s", False)
-    two = api.tPLS(4, dtype=dtype, algorithm="xcov")
+    opt["xcov_ssq_with_s"] = False
+    two = api.tPLS(4, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))
     two.fit(x, y)
     assert (calls["recon_r2"], calls["xcov_ssq"], calls["xcov"]) == (1, 1, 1)
     assert one.n_iter_ == two.n_iter_
@@ -714,18 +716,18 @@ def test_xcov_deflate_kernel_equals_deflating_then_building_s(be, dtype, I, A, B
 def test_xcov_masked_fit_deflates_inside_the_rebuild_of_s(api, monkeypatch, dtype, shape, M):
     """One block with missing values: per component the final score (one read), then ONE read + write that deflates X and builds
     [S; S2] of the next component (FitRun._finish_xcov_masked_fused) instead of a read + write and a read.  Same fit."""
-    from cmtf_pls_amd.engine import NipalsEngine
+    opt = {}                                              # EngineOptions fields this test overrides
     R = 4 if shape[0] > 100 else 2
     x, y, _ = O.import_synthetic(shape, M, 4, error=0.1, seed=43)
     x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
     if dtype == "float32":
         x, y = _f32(x), _f32(y)
     calls = _count_calls(monkeypatch, ["xcov", "xcov_deflate", "score_deflate"])
-    one = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    one = api.tPLS(R, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))
     one.fit(x, y)
     assert (calls["xcov"], calls["xcov_deflate"], calls["score_deflate"]) == (1, R - 1, 1)
-    monkeypatch.setattr(NipalsEngine, "xcov_deflate_build", False)
-    two = api.tPLS(R, dtype=dtype, algorithm="xcov")
+    opt["xcov_deflate_build"] = False
+    two = api.tPLS(R, dtype=dtype, algorithm="xcov", options=default_options().but(**opt))
     two.fit(x, y)
     assert (calls["xcov"], calls["xcov_deflate"], calls["score_deflate"]) == (1 + R, R - 1, 1 + R)
     assert one.n_iter_ == two.n_iter_

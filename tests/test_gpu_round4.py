@@ -1,0 +1,320 @@
+"""Round 4 on the HIP path: observable path selection, the lifted shape limits, per-sample selection of the projection form,
+the conditioning guard of the uncentred xcov form, every branch of the pipelined inner loop.
+
+* `fit_report_` / `projection_report_` name what ran (VERDICT r3 "Next" #2); one test per fallback.
+* algorithm="xcov" with more than 64 responses (tpls.py:100-102 has no limit on M): S in response tiles of 64.
+* transform / predict of a batch WITH missing values: complete samples keep their one-pass MTTKRP scores, only the
+  incomplete ones take the masked sequence (tpls.py:128-142 works sample by sample) -- one block, two and THREE coupled
+  blocks (cmtf.py:179-210 takes any number).
+* uncentred xcov declined for badly offset data; the speculative branches of the pipelined loop on the GPU;
+  the one-launch small fit with more components than rank(X_c).
+"""
+import numpy as np
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+import oracle as O
+from cmtf_pls_amd.engine import EngineOptions, default_options
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import cmtf_pls_amd
+    return cmtf_pls_amd
+
+
+def _f32(a):
+    return a.astype(np.float32).astype(np.float64)
+
+
+def _normwise(got, want):
+    got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
+    if got.ndim == 1:
+        got, want = got[:, None], want[:, None]
+    scale = np.abs(want).max(axis=0, keepdims=True)
+    return float((np.abs(got - want) / (np.abs(want) + scale)).max())
+
+
+# ---- reports ---------------------------------------------------------------------------------------------------------------
+def test_fit_report_names_the_forms_that_ran(api):
+    x, y, _ = O.import_synthetic((512, 64, 64), 8, 4, error=0.1, seed=3)
+    x, y = _f32(x), _f32(y)
+    d = api.tPLS(3, dtype="float32")
+    d.fit(x, y)
+    rep = d.fit_report_
+    assert rep["form"] == "regular" and rep["algorithm"] == "direct" and rep["backend"] == "hip"
+    assert rep["y_side"] == "fused into the sweeps" and rep["storage"] == ["float32"] and rep["declined"] == [] and not rep["graphs"]
+    g = api.tPLS(3, dtype="float32", graphs=True)
+    g.fit(x, y)
+    assert g.fit_report_["graphs"] is True and g.fit_report_["graph_error"] is None
+    xc = api.tPLS(3, dtype="float32", algorithm="xcov")
+    xc.fit(x, y)
+    rep = xc.fit_report_
+    assert rep["algorithm"] == "xcov" and rep["raw"] and rep["one_read"] and rep["pipelined"] and not rep["x_written"]
+    assert rep["x_passes_per_component"] == "1 read" and rep["declined"] == []
+    assert rep["pipeline"]["iterations"] == sum(xc.n_iter_)
+    # a row too short for the one-read kernel: reported, not silent
+    xs, ys, _ = O.import_synthetic((256, 16, 16), 4, 3, error=0.1, seed=4)
+    s = api.tPLS(3, dtype="float32", algorithm="xcov")
+    s.fit(_f32(xs), _f32(ys))
+    assert s.fit_report_["one_read"] is False and any("one read per component declined" in w for w in s.fit_report_["declined"])
+    # missing values: rebuilds S per component, deflation inside the rebuild
+    xn = x.copy()
+    xn[np.random.default_rng(5).random(x.shape) < 0.2] = np.nan
+    n = api.tPLS(3, dtype="float32", algorithm="xcov")
+    n.fit(xn, y)
+    rep = n.fit_report_
+    assert rep["missing"] == [True] and not rep["raw"] and "deflation inside the rebuild of S" in rep["x_passes_per_component"]
+
+
+@pytest.mark.small_fit
+def test_fit_report_of_the_one_launch_small_fit(api):
+    x, y, _ = O.import_synthetic((200, 10, 8), 4, 3, error=0.1)
+    m = api.tPLS(3, algorithm="xcov", graphs=True)               # neither applies to the one-launch form: the report says so
+    m.fit(x, y)
+    assert m.fit_report_["form"] == "small_fit" and m.fit_report_["launches"] == 1 and "do not apply" in m.fit_report_["note"]
+    r = api.tPLS(3, options=EngineOptions(small_fit=False))
+    r.fit(x, y)
+    assert r.fit_report_["form"] == "regular"
+
+
+# ---- more than 64 responses --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["tpls_f32", "tpls_f64", "coupled", "nan"])
+def test_xcov_with_96_responses(api, case):
+    """The reference takes any number of responses (tpls.py:100-102).  M = 96: S = Y^T X_(0) is built in two response tiles
+    (cmtfpls_xcov_*), the inner loop runs on S through the general launches; equal to the direct loop and the oracle."""
+    rng = np.random.default_rng(21)
+    I, M, R = 384, 96, 3
+    lat = rng.normal(size=(I, 5))
+    x = np.einsum("ir,jr,kr->ijk", lat, rng.normal(size=(32, 5)), rng.normal(size=(64, 5))) + 0.1 * rng.normal(size=(I, 32, 64))
+    y = lat @ rng.normal(size=(5, M)) + 0.1 * rng.normal(size=(I, M))
+    x, y = _f32(x), _f32(y)
+    dtype = "float64" if case == "tpls_f64" else "float32"
+    if case == "nan":
+        x[rng.random(x.shape) < 0.2] = np.nan
+    blocks = [x, _f32(lat @ rng.normal(size=(5, 48)) + 0.1 * rng.normal(size=(I, 48)))] if case == "coupled" else [x]
+    coupled = case == "coupled"
+    make = lambda alg: (api.ctPLS if coupled else api.tPLS)(R, dtype=dtype, algorithm=alg)
+    a, d = make("xcov"), make("direct")
+    for m in (a, d):
+        m.fit(blocks if coupled else x, y)
+    rep = a.fit_report_
+    assert rep["algorithm"] == "xcov" and rep["responses"] == M and "2 response tiles" in rep["s_build"]
+    assert any("more than 64 responses" in w for w in rep["declined"])            # (the pipelined single-call iteration is M <= 64)
+    assert d.fit_report_["y_side"] == "separate launches"
+    Ta, Td = (a.factor_T, d.factor_T) if coupled else (a.X_factors[0], d.X_factors[0])
+    tol = 1e-9 if dtype == "float64" else 1e-5
+    assert list(a.n_iter_) == list(d.n_iter_)
+    assert _normwise(Ta, Td) <= tol
+    fit = O.fit_ctpls(blocks, y, R) if coupled else O.fit_tpls(x, y, R)
+    assert list(a.n_iter_) == list(fit.n_iter)
+    assert _normwise(Ta, fit.T) <= tol and _normwise(a.Y_factors[1], fit.Q) <= tol
+    assert_allclose(a.R2Y, fit.r2y, rtol=0, atol=tol)
+
+
+def test_xcov_kernel_response_tiles_equal_one_gemm(api):
+    """cmtfpls_xcov_{f32,f64} and cmtfpls_xcov_ssq_* at M = 64, 65, 96, 130 against torch's f64 matmul."""
+    from cmtf_pls_amd.backend import HipBackend
+    be = HipBackend("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for dtype in (torch.float32, torch.float64):
+        X = torch.randn(700, 24 * 32, generator=g, dtype=torch.float64).to(dtype).cuda()
+        for M in (64, 65, 96, 130):
+            Y = torch.randn(700, M, generator=g, dtype=torch.float64).cuda()
+            want = Y.T @ X.double()
+            S = be.xcov(X, Y, False)
+            assert float((S - want).abs().max()) <= 1e-11 * float(want.abs().max()) + 1e-12, (dtype, M)
+            mean = X.double().mean(dim=0)
+            S2, ssq = be.xcov_ssq(X, Y, mean, out=be.empty(M, X.shape[1]))
+            assert torch.equal(S2, S)
+            assert abs(float(ssq.item()) - float(((X.double() - mean) ** 2).sum())) <= 1e-10 * float(ssq.item())
+            Xn = X.clone()
+            Xn[::7, ::5] = float("nan")
+            Sm = be.xcov(Xn, Y, True)
+            wantm = Y.T @ torch.nan_to_num(Xn.double(), nan=0.0)
+            assert float((Sm - wantm).abs().max()) <= 1e-11 * float(wantm.abs().max()) + 1e-12, (dtype, M)
+
+
+# ---- projection: per-sample form ---------------------------------------------------------------------------------------------
+def _coupled_data(n_blocks, I=600, seed=8):
+    rng = np.random.default_rng(seed)
+    lat = rng.normal(size=(I, 4))
+    x = _f32(np.einsum("ir,jr,kr->ijk", lat, rng.normal(size=(32, 4)), rng.normal(size=(64, 4))) + 0.1 * rng.normal(size=(I, 32, 64)))
+    blocks = [x]
+    if n_blocks >= 2:
+        blocks.append(_f32(lat @ rng.normal(size=(4, 512)) + 0.1 * rng.normal(size=(I, 512))))
+    if n_blocks >= 3:
+        blocks.append(_f32(np.einsum("ir,jr,kr->ijk", lat, rng.normal(size=(8, 4)), rng.normal(size=(16, 4))) + 0.1 * rng.normal(size=(I, 8, 16))))
+    y = _f32(lat @ rng.normal(size=(4, 6)) + 0.1 * rng.normal(size=(I, 6)))
+    return blocks, y
+
+
+@pytest.mark.parametrize("n_blocks", [1, 2, 3])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_transform_of_a_partly_incomplete_batch(api, n_blocks, dtype):
+    """30 % of the SAMPLES have missing values.  The complete samples get exactly the scores they get when transformed on
+    their own (one-pass MTTKRP: a sample's result does not depend on the rest of the batch), the incomplete ones the
+    reference's masked sequence (oracle); one block and two coupled blocks in registers, three through compact copies."""
+    blocks, y = _coupled_data(n_blocks)
+    coupled = n_blocks > 1
+    R = 5
+    m = (api.ctPLS if coupled else api.tPLS)(R, dtype=dtype)
+    m.fit(blocks if coupled else blocks[0], y, max_iter=40)
+    fit = (O.fit_ctpls(blocks, y, R, max_iter=40) if coupled else O.fit_tpls(blocks[0], y, R, max_iter=40))
+    rng = np.random.default_rng(9)
+    new = [b[:400].copy() for b in blocks]
+    bad = rng.random(400) < 0.3
+    for b in new:
+        hole = rng.random(b.shape) < 0.25
+        hole[~bad] = False
+        b[hole] = np.nan
+    new[0][np.flatnonzero(bad)[0]] = np.nan                     # an EMPTY row in the first block: NaN score (missingvals.py:37)
+    arg = new if coupled else new[0]
+    got = m.transform(arg)
+    rep = m.projection_report_
+    assert rep["incomplete_rows"] == int(bad.sum())
+    if n_blocks <= 2:
+        assert rep["form"].startswith("one-pass MTTKRP for the complete samples + masked sequence in registers"), rep
+    else:
+        assert rep["form"].startswith("one-pass MTTKRP for the complete samples + sequential passes on copies"), rep
+    want = O.transform(fit, arg)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want).any(axis=1)
+    tol = 2e-5 if dtype == "float32" else 1e-8
+    assert _normwise(got[ok], want[ok]) <= tol
+    alone = m.transform([b[~bad] for b in new] if coupled else new[0][~bad])
+    assert m.projection_report_["form"].startswith("one-pass MTTKRP (one read")
+    assert np.array_equal(got[~bad], alone)                      # bit for bit: the complete samples never saw the masked path
+    # the old behaviour (every row of such a batch through the masked sequence) stays selectable and agrees
+    every = (api.ctPLS if coupled else api.tPLS)(R, dtype=dtype, options=default_options().but(project_split_rows=False))
+    every.fit(blocks if coupled else blocks[0], y, max_iter=40)
+    got2 = every.transform(arg)
+    assert np.array_equal(np.isnan(got2), np.isnan(want)) and _normwise(got2[ok], want[ok]) <= tol
+    p = m.predict(arg)
+    wantp = O.predict(fit, arg)
+    assert _normwise(p[ok], wantp[ok]) <= 10 * tol
+
+
+def test_transform_of_a_mostly_incomplete_batch_skips_the_mttkrp_attempt(api):
+    blocks, y = _coupled_data(1)
+    m = api.tPLS(4, dtype="float32")
+    m.fit(blocks[0], y, max_iter=30)
+    new = blocks[0][:300].copy()
+    new[np.random.default_rng(3).random(new.shape) < 0.3] = np.nan             # every sample has holes (BASELINE configs[3])
+    got = m.transform(new)
+    rep = m.projection_report_
+    assert rep["probe_incomplete_fraction"] == 1.0 and rep["form"].startswith("masked sequence, every row in registers"), rep
+    want = O.transform(O.fit_tpls(blocks[0], y, 4, max_iter=30), new)
+    assert _normwise(got, want) <= 2e-5
+
+
+# ---- ADVICE r3 -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("offset,raw", [(20.0, True), (1e6, False)])
+def test_uncentred_xcov_is_declined_for_badly_offset_data(api, offset, raw):
+    """xcov on the uncentred tensor works by cancellation (error ~ 1e-16 |mean| / spread): taken at 20 x the spread, declined
+    at 1e6 x (`EngineOptions.xcov_raw_max_offset` = 1e4) in favour of the centred private copy -- which matches the oracle as
+    a centred fit does; forcing the raw form there loses the digits the guard protects."""
+    x, y, _ = O.import_synthetic((300, 16, 64), 5, 4, error=0.1, seed=12)
+    x = x + offset
+    m = api.tPLS(4, algorithm="xcov")
+    m.fit(x, y)
+    rep = m.fit_report_
+    assert rep["raw"] is raw
+    assert any("uncentred xcov form declined: max|column mean|" in w for w in rep["declined"]) == (not raw)
+    fit = O.fit_tpls(x, y, 4)
+    assert list(m.n_iter_) == list(fit.n_iter)
+    err = _normwise(m.X_factors[0], fit.T)
+    assert err <= 1e-8, err
+    assert_allclose(m.R2X, fit.r2x[0], rtol=0, atol=1e-9)
+    if not raw:
+        forced = api.tPLS(4, algorithm="xcov", options=default_options().but(xcov_raw_max_offset=float("inf")))
+        forced.fit(x, y)
+        assert forced.fit_report_["raw"] is True
+        print(f"offset 1e6: centred copy {err:.2e}, forced uncentred form {_normwise(forced.X_factors[0], fit.T):.2e} (normwise T vs oracle)")
+
+
+def test_every_branch_of_the_pipelined_inner_loop_runs_on_the_gpu(api):
+    """FitRun._inner_loop_xcov_pipelined on the device, every branch forced and counted (`fit_report_["pipeline"]`), each time bit-equal
+    to the loop that waits after every iteration, the caller's X untouched:
+      redone  -- a squaring budget too small for the rank-1 extraction: the tail of the iteration is re-enqueued while a
+                 speculative iteration built on the unfinished loadings is already in flight and must be discarded;
+      unused  -- the loop converges although the norms did not predict it: the iteration enqueued ahead ran for nothing;
+      waited  -- the norms predicted convergence, it did not come: no speculation, the GPU idles through one round trip."""
+    from cmtf_pls_amd.backend import HipBackend
+    from cmtf_pls_amd.engine import NipalsEngine
+    x, y, _ = O.import_synthetic((1024, 32, 64), 6, 10, error=0.3, seed=17)
+    X = torch.from_numpy(_f32(x)).float().cuda()
+    Y = torch.from_numpy(_f32(y)).cuda()
+    X0 = X.clone()
+    be = HipBackend("cuda:0")
+
+    def fit(pipeline, tol, max_iter=100, budget=None, R=3):
+        eng = NipalsEngine(be, None, EngineOptions(small_fit=False, xcov_pipeline=pipeline))
+        run = eng.begin([X], Y.clone(), R, False, algorithm="xcov", owned=[False])
+        run.tol = tol
+        dus = []
+        for a in range(R):
+            run.start_component(a)
+            if budget is not None:
+                run.sq_budget = [budget]
+            if pipeline:
+                run.inner_loop(a, max_iter, tol)
+            else:
+                for it in range(max_iter):
+                    du = run.iterate(it)
+                    dus.append((a, it, du))
+                    if du is not None and du < tol:
+                        break
+            run.finish_component(a)
+        st = run.result()
+        return st, dus
+
+    def same(a, b):
+        assert a.n_iter == b.n_iter
+        assert torch.equal(a.T, b.T) and torch.equal(a.Q, b.Q) and torch.equal(a.blocks[0].loadings[0], b.blocks[0].loadings[0])
+
+    # redone: one squaring (+ 4 spare on a component's first iteration) cannot separate sigma_2 / sigma_1 ~ 0.9
+    wait, dus = fit(False, 1e-8, budget=1)
+    pipe, _ = fit(True, 1e-8, budget=1)
+    same(pipe, wait)
+    stats = pipe.report["pipeline"]
+    assert stats["redone"] > 0 and stats["ahead"] > 0, stats
+    # unused: a tolerance every second norm meets (no two norms yet to predict from): the iteration enqueued ahead is discarded
+    wait_u, _ = fit(False, 1e30)
+    pipe_u, _ = fit(True, 1e30)
+    same(pipe_u, wait_u)
+    assert pipe_u.report["pipeline"]["unused"] > 0 and pipe_u.n_iter == [2, 2, 2], (pipe_u.report["pipeline"], pipe_u.n_iter)
+    # waited: a tolerance between the predicted norm d_{k-1}^2 / d_{k-2} and the norm d_k that actually came (the decay slows down)
+    seq = [du for (a, it, du) in dus if a == 0 and du is not None]
+    ks = [k for k in range(2, len(seq)) if seq[k - 1] ** 2 / seq[k - 2] < 0.9 * seq[k]]
+    assert ks, ("the first component's norms never decay slower than predicted: pick other data", seq[:12])
+    k = ks[0]
+    tol = float(np.sqrt((seq[k - 1] ** 2 / seq[k - 2]) * seq[k]))
+    wait_w, _ = fit(False, tol, R=1)
+    pipe_w, _ = fit(True, tol, R=1)
+    same(pipe_w, wait_w)
+    assert pipe_w.report["pipeline"]["waited"] > 0, (pipe_w.report["pipeline"], tol, seq[:k + 2])
+    assert torch.equal(X, X0)                                    # owned=[False]: the caller's tensor is never written
+
+
+@pytest.mark.small_fit
+def test_more_components_than_the_rank_of_x_on_both_small_fit_paths(api, small_fit_mode):
+    """R exceeds rank(X_c) (the two paths of a small float64 fit stopped after different iteration counts
+    there).  What the reference defines is pinned against the oracle on BOTH paths: every component up to the rank
+    (factors, iteration counts), R2X / R2Y of all components, predictions.  Beyond the rank the deflated X is rounding
+    noise: loadings and iteration counts of those components are noise in the reference too and are not compared."""
+    x, y, _ = O.import_synthetic((40, 6, 5), 3, 2, error=0.0, seed=3)          # X has CP rank 2: X_c has rank 2
+    R = 4
+    m = api.tPLS(R, options=small_fit_mode)
+    m.fit(x, y)
+    assert m.fit_report_["form"] == ("small_fit" if small_fit_mode.small_fit else "regular")
+    fit = O.fit_tpls(x, y, R)
+    assert list(m.n_iter_[:2]) == list(fit.n_iter[:2])
+    assert _normwise(m.X_factors[0][:, :2], fit.T[:, :2]) <= 1e-9
+    assert_allclose(m.R2X, fit.r2x[0], rtol=0, atol=1e-9)
+    assert_allclose(m.R2Y, fit.r2y, rtol=0, atol=1e-9)
+    assert np.all(np.isfinite(m.coef_)) and np.all(np.isfinite(m.X_factors[0]))
+    assert_allclose(m.predict(x[:7]), O.predict(fit, x[:7]), rtol=1e-7, atol=1e-9)

@@ -16,8 +16,7 @@ from cmtf_pls_amd.synthetic import synthetic_shard_device  # noqa: E402
 
 algo = sys.argv[1] if len(sys.argv) > 1 else "xcov"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-if os.environ.get("CMTFPLS_NO_PIPELINE"):
-    E.NipalsEngine.xcov_pipeline = False
+OPTS = E.EngineOptions(xcov_pipeline=not os.environ.get("CMTFPLS_NO_PIPELINE"))
 acc = defaultdict(float)
 
 
@@ -38,7 +37,7 @@ for name in ("start_component", "inner_loop", "finish_component", "result"):
     timed(E.FitRun, name)
 timed(E.NipalsEngine, "begin")
 dev = torch.device("cuda:0")
-eng = E.NipalsEngine(HipBackend(dev), None)
+eng = E.NipalsEngine(HipBackend(dev), None, OPTS)
 X, Y = synthetic_shard_device((65536, 128, 128), 16, 10, error=0.1, seed=215, device=dev)
 for i in range(N + 1):
     if i == 1:

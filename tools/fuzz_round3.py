@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle as O  # noqa: E402
 from cmtf_pls_amd import ctPLS, tPLS  # noqa: E402
 from cmtf_pls_amd.backend import HipBackend  # noqa: E402
-from cmtf_pls_amd.engine import NipalsEngine  # noqa: E402
+from cmtf_pls_amd.engine import EngineOptions, set_default_options  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -70,7 +70,7 @@ for name, key in (("project_rows", "rows"), ("project_rows2", "rows2")):
         return out
     setattr(HipBackend, name, wrapped)
 
-NipalsEngine.small_fit = False
+set_default_options(EngineOptions(small_fit=False))
 for case in range(N // 2):
     f32 = bool(rng.integers(2))
     coupled = bool(rng.integers(2))
@@ -114,11 +114,9 @@ for case in range(N // 3):
     R = min(R, A * B, I - 1)               # (beyond the rank of the centred X the loop iterates on rounding noise: nothing to compare)
     shape = (I, A, B) if order3 else (I, B)
     x, y, _ = O.import_synthetic(shape, M, 3, error=0.2, seed=int(rng.integers(1 << 30)))
-    NipalsEngine.small_fit = True
-    one = tPLS(R)
+    one = tPLS(R, options=EngineOptions(small_fit=True))
     one.fit(x, y)
-    NipalsEngine.small_fit = False
-    reg = tPLS(R)
+    reg = tPLS(R, options=EngineOptions(small_fit=False))
     reg.fit(x, y)
     n_small += 1
     assert one.n_iter_ == reg.n_iter_, ("fit_small n_iter", shape, M, R, one.n_iter_, reg.n_iter_)
@@ -188,4 +186,4 @@ for case in range(N // 3):
     e = normwise(Tx, Td)
     assert e < (5e-5 if f32 else 1e-7), ("xcov vs direct", kind, (I, A, B), M, R, dtype, e)
     assert np.abs(np.asarray(xc.R2Y) - d.R2Y).max() < (1e-5 if f32 else 1e-9), ("xcov R2Y", kind)
-print(f"xcov (one read, pipelined, paired S build) vs direct: {n_x} random fits ok; pipeline {getattr(xc._engine, 'pipeline_stats', None) if hasattr(xc, '_engine') else ''}", flush=True)
+print(f"xcov (one read, pipelined, paired S build) vs direct: {n_x} random fits ok; last fit's pipeline {xc.fit_report_.get('pipeline')}", flush=True)
