@@ -67,6 +67,9 @@ def parse(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="timed windows of exactly --steps iterations each; value = median")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 262144x256x256 leg (BASELINE.json north_star)")
     ap.add_argument("--north-star-steps", type=int, default=10)
+    ap.add_argument("--capture-collectives", type=int, default=0,
+                    help="N > 1: capture the two per-iteration all-reduces inside the iteration's HIP graph (EngineOptions.capture_collectives; "
+                         "falls back to the segment-wise form when the capture fails)")
     return ap.parse_args(argv)
 
 
@@ -335,7 +338,7 @@ def main():
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from cmtf_pls_amd.backend import HipBackend
-    from cmtf_pls_amd.engine import Comm, NipalsEngine
+    from cmtf_pls_amd.engine import Comm, EngineOptions, NipalsEngine
 
     class TimedComm(Comm):
         """Comm whose all-reduces are bracketed by HIP events on the launch stream while `on` is set (the
@@ -364,7 +367,7 @@ def main():
     timer = EventTimer(be, ["mode0_contract", "mode0_contract_yq", "score", "score_gram", "rank1", "q_update", "gram_tn",
                             "rowdot", "deflate"])
     comm = TimedComm(force=force_dist) if backend else None
-    eng = NipalsEngine(be, comm)
+    eng = NipalsEngine(be, comm, EngineOptions(capture_collectives=bool(args.capture_collectives)))
 
     # ---- timed leg: K direct NIPALS iterations of component 0 -------------------------------
     Xw, Yw = X.clone(), Y.clone()
@@ -431,6 +434,8 @@ def main():
             run._graph_error = repr(e)
             elapsed, windows = eager_elapsed, eager_windows
     graphs_used, graph_error = run.use_graphs, run._graph_error
+    collectives_in_graph = run._collectives_captured is True
+    iter_notes = list(run.notes)
     run.finish_component(0)                        # exercises the deflation sweep once (timed below by events)
 
     es = X.element_size()
@@ -495,9 +500,20 @@ def main():
         for e0, e1, nb in comm.pairs:
             by_size.setdefault(nb, []).append(e0.elapsed_time(e1))
         comm_info = {"backend": backend, "ranks": dist.get_world_size(), "forced_single_rank": force_dist,
+                     "in_graph": collectives_in_graph, "notes": iter_notes,
                      "allreduce_ms_by_bytes": {str(nb): sum(v) / len(v) for nb, v in sorted(by_size.items())},
                      "allreduce_ms_per_step": sum(sum(v) for v in by_size.values()) / max(args.steps * reps, 1),
                      "collectives_per_step": len(comm.pairs) / max(args.steps * reps, 1)}
+    # N > 1: what every rank spent where (a scaling record must explain itself): the two sweeps, the rank-1 chain, the Y
+    # update and the all-reduces of the eager windows (HIP events), next to the rank's own graph-replay step
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "rows": rows, "contraction_ms": kern["mode0_contract"]["ms"], "score_ms": kern["score"]["ms"],
+                "rank1_ms": kern["rank1"]["ms"], "q_update_ms": (kern.get("q_update") or {}).get("ms"),
+                "allreduce_ms_per_step": comm_info["allreduce_ms_per_step"] if comm_info else None,
+                "eager_ms_per_step": eager_elapsed / args.steps * 1e3, "ms_per_step": elapsed / args.steps * 1e3}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     del Xw, Yw, run
 
     # ---- sec-to-fit leg (default tol / max_iter, like the reference's fit()) ----------------
@@ -532,6 +548,9 @@ def main():
                             "iters_per_sec_in_fit": sum(sx.n_iter) / xs,
                             "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
                             "max_abs_dT_vs_direct": float((sx.T - st.T).abs().max())}
+        # which forms ran (engine.FitRun.build_report): algorithm after fallbacks, passes over X, centred copy or the caller's
+        # tensor, pipelined, graph replay -- and every fast form the shape declined, in words
+        fit_info["path"] = {"direct": st.report, "xcov": sx.report}
         # opt-in mixed precision of the S build (f32 MFMA, csrc/mixed.hip): reported, never the headline
         sm, xm_first = timed_fit(algorithm="xcov", mixed=True)
         sm, xm = timed_fit(algorithm="xcov", mixed=True)
@@ -590,8 +609,8 @@ def main():
                        "x_reads_per_step": 2, "hip_graphs": bool(graphs_used), "graph_error": graph_error,
                        "eager_ms_per_step": eager_elapsed / args.steps * 1e3,
                        "eager_ms_per_step_min_max": [min(eager_windows) / args.steps * 1e3, max(eager_windows) / args.steps * 1e3]},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "collectives": comm_info, "mfma": mfma, "fit": fit_info,
-            "north_star": north,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "collectives": comm_info, "per_rank": per_rank,
+            "mfma": mfma, "fit": fit_info, "north_star": north,
         }
         print(json.dumps(out), flush=True)
     if backend:

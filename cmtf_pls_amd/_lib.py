@@ -25,6 +25,7 @@ SIGNATURES = {
     "cmtfpls_xcov_iterate_blocks_f64": (c_int, [ctypes.POINTER(XcovBlock), c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "cmtfpls_abi_version": (c_int, []),
     "cmtfpls_last_error": (c_char_p, []),
+    "cmtfpls_clear_error": (c_int, []),
     "cmtfpls_status_to_host": (c_int, [_P, _P, c_size_t, _P, _P]),
     "cmtfpls_colstats_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "cmtfpls_colstats_f32": (c_int, [_P, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "cmtfpls_mttkrp_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int, _P, c_int, _P]),
     "cmtfpls_score_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
     "cmtfpls_score_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P]),
+    "cmtfpls_score_s_f64": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "cmtfpls_deflate_contract_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "cmtfpls_deflate_contract_yq_f32": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_size_t, _P]),
     "cmtfpls_deflate_contract_yq_f64": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P, _P, c_size_t, _P]),

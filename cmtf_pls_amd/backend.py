@@ -43,6 +43,10 @@ class HipBackend:
             self._ws[key] = buf
         return buf
 
+    def clear_error(self) -> bool:
+        """After a failed HIP-graph capture: reset the runtime's pending error so that the next launch is not blamed for it."""
+        return bool(self.lib.cmtfpls_clear_error())
+
     def empty(self, *shape, dtype=torch.float64) -> torch.Tensor:
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
@@ -329,6 +333,13 @@ class HipBackend:
     # -- K3: tpls.py:92-99 / missingvals.py:23-38 --------------------------------------------
     def score(self, X2, A, B, wA, wB, rowcnt, out) -> torch.Tensor:
         _lib.check(self._fn("score", X2)(_ptr(X2), X2.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(rowcnt), _ptr(out), self._stream()), "score")
+        return out
+
+    def score_s(self, S, A, B, wA, wB, out) -> torch.Tensor:
+        """out[m] = S[m, :] . kron(wA, wB) for the M rows of a cross-covariance S (or a one-row "tensor" such as the column
+        means): cmtfpls_score_s_f64 -- few long rows take one workgroup each, which cmtfpls_score_* never does for samples."""
+        assert S.dtype == torch.float64 and S.is_contiguous()
+        _lib.check(self.lib.cmtfpls_score_s_f64(_ptr(S), S.shape[0], A, B, _ptr(wA), _ptr(wB), _ptr(out), self._stream()), "score_s")
         return out
 
     def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha: float = 1.0,

@@ -15,8 +15,6 @@
 // exact pass with Z, sign rule on the last mode), run inside the workgroup with G in LDS.
 // Limits (the caller falls back to one refit per fold on the regular engine otherwise): X of order 2 or 3 without
 // missing values, min(A, B) <= 64, M <= 64, R <= 16, and the per-workgroup vectors must fit 150 KB of LDS.
-#include <stdlib.h>
-
 #include "common.hpp"
 
 namespace cmtfpls {
@@ -590,13 +588,13 @@ int cmtfpls_fit_small_f64(const double* X, const double* Y, int I, int A, int B,
   a.lds_xy_offset = xy_off;
   a.U_out = U; a.WA_out = WA; a.WB_out = WB; a.Q_out = Q; a.coef_out = coef; a.ssq_out = ssq; a.xmean_out = x_mean; a.ymean_out = y_mean;
   a.flag_out = flag;
-  // (tuning hook: CMTFPLS_FIT_SMALL_NT=256 runs the 256-thread instance)
-  const char* nt_env = getenv("CMTFPLS_FIT_SMALL_NT");
-  if (nt_env && atoi(nt_env) == 256) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(loo_tpls_kernel<256>, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
-    return check_launch("fit_small");
-  }
+  // (the 256-thread instance was measured against this one in round 3, profiles/r03q_small_fit.txt; build with
+  // -DCMTFPLS_FIT_SMALL_NT=256 to repeat that: a compile-time variant for tools, no run-time hook in the product path)
+#if defined(CMTFPLS_FIT_SMALL_NT) && CMTFPLS_FIT_SMALL_NT == 256
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(loo_tpls_kernel<256>, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("fit_small");
+#endif
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loo_tpls_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(loo_tpls_kernel<1024>, dim3(1), dim3(1024), lds, (hipStream_t)stream, a);
   return check_launch("fit_small");

@@ -195,9 +195,6 @@ __global__ __launch_bounds__(256) void mttkrp_jk_kernel(const T* __restrict__ X,
         for (int p = 0; p < CH; ++p)
 #pragma unroll
           for (int e = 0; e < V; ++e) {
-#ifdef CMTFPLS_MTTKRP_EXP_SKIP      // timing experiment only (wrong results): issue 1 of every EXP_SKIP MFMAs, all loads kept
-            if ((p * V + e) % CMTFPLS_MTTKRP_EXP_SKIP != 0) { asm volatile("" :: "v"(buf[p].e[e])); continue; }
-#endif
             accs[p % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)buf[p].e[e], breg[(CC < 0 ? 0 : CC) * CH + p][e], accs[p % NACC], 0, 0, 0);
           }
       } else {
@@ -308,9 +305,6 @@ __global__ __launch_bounds__(256) void mttkrp_kj_kernel(const T* __restrict__ X,
         for (int n = 0; n < NL; ++n)
 #pragma unroll
           for (int e = 0; e < V; ++e) {
-#ifdef CMTFPLS_MTTKRP_EXP_SKIP      // timing experiment only (wrong results): issue 1 of every EXP_SKIP MFMAs, all loads kept
-            if (((h * NL + n) * V + e) % CMTFPLS_MTTKRP_EXP_SKIP != 0) { asm volatile("" :: "v"(buf[h][n].e[e])); continue; }
-#endif
             acc[n][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)buf[h][n].e[e], wa, acc[n][e], 0, 0, 0);
           }
       }

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024) void rank1_final_kernel(const double* __restr
 
 // The last kernel of the extraction AND the score of a FEW LONG rows with the loading it has just formed (round 3): inside the
 // cross-covariance loop the rank-1 extraction of Z is always followed by Y^T t = S (wA (x) wB) on the M rows of S (M <= 64 rows of
-// >= 8192 elements: cmtfpls_score_f64 takes them one 1024-thread workgroup per row, score_fewrows_kernel) -- one launch of pure
+// >= 8192 elements: cmtfpls_score_s_f64 takes them one 1024-thread workgroup per row, score_fewrows_kernel) -- one launch of pure
 // latency less per iteration.  Every workgroup normalises and sign-fixes the two vectors itself (a few hundred elements, into
 // LDS; workgroup 0 also stores them and the flags), then takes its row exactly as score_fewrows_kernel does: same per-lane
 // order, same block sum, the same bits.
@@ -463,7 +463,7 @@ int cmtfpls_rank1_score_f64(const double* Z, int A, int B, double* wA, double* w
   if (M > 64 || P < 8192 || (B % 2) != 0 || ((size_t)(((A + 1) & ~1) + B) * sizeof(double)) > 60 * 1024 ||
       (reinterpret_cast<uintptr_t>(S) & 15) != 0) {       // outside the few-long-rows form: the two entries, one after the other
     int rc = cmtfpls_rank1_f64(Z, A, B, wA, wB, nullptr, info, n_squarings, ws, ws_bytes, stream);
-    if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(S, M, A, B, wA, wB, nullptr, tq, stream);
+    if (rc == CMTFPLS_OK) rc = cmtfpls_score_s_f64(S, M, A, B, wA, wB, tq, stream);
     return rc;
   }
   return rank1_run(Z, A, B, wA, wB, nullptr, info, n_squarings, ws, ws_bytes, stream, S, M, tq);

@@ -24,6 +24,13 @@ int check_launch(const char* what) {
 extern "C" {
 int cmtfpls_abi_version(void) { return 1; }
 const char* cmtfpls_last_error(void) { return cmtfpls::g_err; }
+int cmtfpls_clear_error(void) {
+  // a failed stream capture (a collective whose backend cannot be captured, ...) leaves the runtime's per-thread "last error" set;
+  // every entry of this library reports hipGetLastError() after its launches and would blame the next, innocent, launch
+  const hipError_t e = hipGetLastError();
+  cmtfpls::g_err[0] = 0;
+  return e == hipSuccess ? 0 : 1;
+}
 
 int cmtfpls_status_to_host(const void* src, void* dst_host, size_t bytes, void* event, void* stream) {
   if (!src || !dst_host || bytes == 0) { cmtfpls::set_error("status_to_host: bad argument"); return CMTFPLS_EINVAL; }

@@ -507,7 +507,7 @@ int cmtfpls_xcov_iterate_blocks_f64(const cmtfpls_xcov_block* blocks, int nb, in
       hipLaunchKernelGGL(normalize_to_kernel, dim3(1), dim3(1024), 0, st, k.Z, k.wB, P);
       rc = check_launch("xcov_iterate_blocks: normalize_to");
     }
-    if (rc == CMTFPLS_OK) rc = cmtfpls_score_f64(k.S2 ? k.S2 : k.S, M, k.A, k.B, k.wA, k.wB, nullptr, tq + (int64_t)b * M, stream);   // cmtf.py:106-119
+    if (rc == CMTFPLS_OK) rc = cmtfpls_score_s_f64(k.S2 ? k.S2 : k.S, M, k.A, k.B, k.wA, k.wB, tq + (int64_t)b * M, stream);   // cmtf.py:106-119
   }
   // cmtf.py:120-125: q_new = mean_b tq_b, normalised -- the SUM of the rows normalised is the same vector (the 1 / nb drops out of
   // q / |q|), and summing the rows of a small matrix is what q_update does with its partials: one launch for both steps

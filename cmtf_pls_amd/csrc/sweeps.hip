@@ -1284,7 +1284,7 @@ static constexpr size_t kMaxLoadingsLds = 96 * 1024;
 template <typename T>
 static int run_score(const T* X, int64_t I, int A, int B, const double* wA, const double* wB,
                      const double* rowcnt, double* t, hipStream_t st,
-                     const double* Y = nullptr, int ldy = 0, int M = 0, double* qpart = nullptr) {
+                     const double* Y = nullptr, int ldy = 0, int M = 0, double* qpart = nullptr, bool few_rows_ok = false) {
   if (!X || !wA || !wB || !t || !shape_ok(I, A, B)) { set_error("score: bad argument"); return CMTFPLS_EINVAL; }
   const bool gram = Y != nullptr;
   if (gram && (!qpart || M <= 0 || ldy < M)) { set_error("score_gram: bad argument"); return CMTFPLS_EINVAL; }
@@ -1302,7 +1302,10 @@ static int run_score(const T* X, int64_t I, int A, int B, const double* wA, cons
   const bool gl = lds > kMaxLoadingsLds;               // loadings longer than the LDS: read them through L2
   if (gl) lds = 0;
   const bool v = vec_ok(X, B), m = rowcnt != nullptr;
-  if (!gram && v && !gl && I <= 64 && (int64_t)A * B >= 8192) {      // a few long rows: one 1024-thread workgroup per row
+  // a few long rows, one 1024-thread workgroup per row: ONLY for the rows of a cross-covariance S (cmtfpls_score_s_f64), whose row
+  // count is the number of responses -- the score of a SAMPLE (cmtfpls_score_*) must not depend on how many samples are
+  // passed with it, and this kernel sums in another order than score_kernel
+  if (few_rows_ok && !gram && v && !gl && I <= 64 && (int64_t)A * B >= 8192) {
     if (m) hipLaunchKernelGGL((score_fewrows_kernel<T, true>), dim3((unsigned)I), dim3(1024), lds, st, X, A, B, wA, wB, rowcnt, t);
     else hipLaunchKernelGGL((score_fewrows_kernel<T, false>), dim3((unsigned)I), dim3(1024), lds, st, X, A, B, wA, wB, rowcnt, t);
     return check_launch("score");
@@ -1592,6 +1595,9 @@ int cmtfpls_center_f64(double* X, int64_t I, int64_t P, const double* mean, doub
 }
 int cmtfpls_score_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt, double* t, void* s) {
   return run_score<float>(X, I, A, B, wA, wB, rowcnt, t, (hipStream_t)s);
+}
+int cmtfpls_score_s_f64(const double* S, int M, int A, int B, const double* wA, const double* wB, double* tq, void* s) {
+  return run_score<double>(S, M, A, B, wA, wB, nullptr, tq, (hipStream_t)s, nullptr, 0, 0, nullptr, true);
 }
 int cmtfpls_score_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* rowcnt, double* t, void* s) {
   return run_score<double>(X, I, A, B, wA, wB, rowcnt, t, (hipStream_t)s);

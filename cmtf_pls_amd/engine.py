@@ -47,6 +47,10 @@ class Comm:
         self.rank = dist.get_rank(group) if on else 0
         self.sharded = self.world > 1 or (bool(force) and on)
         self.n_collectives = 0
+        # only RCCL enqueues its collectives as kernels on the caller's stream, i.e. can be captured into a HIP graph; gloo stages
+        # through the host with stream synchronisations, which a capture forbids (and which leave the runtime in an error state)
+        self.backend = str(dist.get_backend(group)) if on else None
+        self.capturable = self.backend == "nccl"
 
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
         if self.sharded:
@@ -680,6 +684,7 @@ class FitRun:
         self.use_graphs = False
         self._graphs = {}
         self._graph_error = None
+        self._collectives_captured = None         # None: not tried; True / False: the outcome of the first capture
         # Fused Y side (M <= 64): u = Y q is formed inside the contraction and Y^T t inside the score
         # kernel, so an iteration has no launch of its own for either; q lives in two buffers that
         # alternate by parity (a captured graph holds their addresses) and |du|^2 is the quadratic form
@@ -828,7 +833,7 @@ class FitRun:
             for b, blk in enumerate(self.blocks):
                 self.eng._rank1(blk, self.Zs[b], self.wA[b], self.wB[b], info=self.status[1 + 2 * b: 3 + 2 * b],
                                 n_squarings=self.sq_budget[b], fac=self.fac[b], tol=self.tol)   # tpls.py:84-90
-                be.score(self.S2[b] if blk.has_miss else self.S[b], blk.A, blk.B, self.wA[b], self.wB[b], None, self.Tq[b])
+                be.score_s(self.S2[b] if blk.has_miss else self.S[b], blk.A, blk.B, self.wA[b], self.wB[b], self.Tq[b])
             if self.qn.data_ptr() != self.Tq.data_ptr():
                 be.scores_mean(self.Tq, self.qn)                                 # cmtf.py:120 (linear in t)
             be.normalize(self.qn)                                                # tpls.py:100-101
@@ -1023,6 +1028,48 @@ class FitRun:
         except Exception as e:                 # capture unsupported in this context: stay eager
             self.use_graphs = False
             self._graph_error = repr(e)
+            self._after_failed_capture()
+
+    def _run_with_collectives(self, key, fn) -> bool:
+        """`EngineOptions.capture_collectives`: one sharded iteration INCLUDING its all-reduces as ONE HIP graph (RCCL enqueues
+        its kernels on the capturing stream), instead of three captured segments with two eager collectives between them.
+        True when `fn`'s work was done (eagerly the first time, by replay afterwards); False when this form is not available
+        -- not asked for, no graph replay, or a capture that failed once (the communicator's backend cannot be captured, e.g.
+        gloo): the caller then runs the segment-wise form, which is what every earlier round ran."""
+        if not (self.use_graphs and self.eng.opt.capture_collectives and self._collectives_captured is not False):
+            return False
+        if not getattr(self.eng.comm, "capturable", False):
+            self._collectives_captured = False
+            self.notes.append(f"all-reduces not captured into the iteration's graph: the {getattr(self.eng.comm, 'backend', None)} "
+                              "backend stages through the host (only RCCL collectives are stream-ordered kernels)")
+            return False
+        g = self._graphs.get(key)
+        if g is not None:
+            g.replay()
+            return True
+        fn()                                   # eager: does this call's work (collectives included) and sizes every workspace
+        try:
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+            self._graphs[key] = g
+            self._collectives_captured = True
+        except Exception as e:                 # the segment-wise form from the next iteration on
+            self._collectives_captured = False
+            self.notes.append("all-reduces not captured into the iteration's graph: " + repr(e)[:200])
+            self._after_failed_capture()
+        return True
+
+    def _after_failed_capture(self) -> None:
+        """A capture that failed leaves the stream's work undone (nothing of the captured pass ran: the eager pass before it did
+        the iteration's work) and the runtime's last error set: drain the device and clear the error before the next launch."""
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        if hasattr(self.eng.be, "clear_error"):
+            self.eng.be.clear_error()
 
     def iterate(self, it: int) -> Optional[float]:
         """One NIPALS inner iteration (tpls.py:80-107).  Returns |u_old - u|_2 (None on the first
@@ -1157,15 +1204,26 @@ class FitRun:
                     seg_y_update()
                 self._run(("fiter", par, budgets, first, have_z), whole)
             else:
-                if first:
-                    if not have_z:
-                        self._run(("fcontract", par), seg_contract)
-                    for b in range(len(self.blocks)):
-                        comm.allreduce(self.Zs[b])
-                    seg_colscale()
-                self._run(("floadings", par, budgets), seg_loadings_scores)
-                comm.allreduce(q_new)
-                self._run(("fyupdate", par), seg_y_update)
+                def whole_sharded():
+                    if first:
+                        if not have_z:
+                            seg_contract()
+                        for b in range(len(self.blocks)):
+                            comm.allreduce(self.Zs[b])
+                        seg_colscale()
+                    seg_loadings_scores()
+                    comm.allreduce(q_new)
+                    seg_y_update()
+                if not self._run_with_collectives(("fiter+ar", par, budgets, first, have_z), whole_sharded):
+                    if first:
+                        if not have_z:
+                            self._run(("fcontract", par), seg_contract)
+                        for b in range(len(self.blocks)):
+                            comm.allreduce(self.Zs[b])
+                        seg_colscale()
+                    self._run(("floadings", par, budgets), seg_loadings_scores)
+                    comm.allreduce(q_new)
+                    self._run(("fyupdate", par), seg_y_update)
             host = self._read_status()
             if not self._update_budgets(host):
                 break
@@ -1412,7 +1470,7 @@ class FitRun:
             blk = self.blocks[b]
             mw = None
             if self.raw:                                                         # uncentred X: X_c w = X w - (mean^T w) 1
-                mw = be.score(blk.mean.view(1, -1), blk.A, blk.B, self.wA[b], self.wB[b], None, be.empty(1))
+                mw = be.score_s(blk.mean.view(1, -1), blk.A, blk.B, self.wA[b], self.wB[b], be.empty(1))
             g = None
             if a > 0 and hasattr(be, "kr_gram_row"):
                 for m, L in enumerate(blk.loadings):                             # Gram of a Khatri-Rao product = Hadamard product
@@ -1529,7 +1587,7 @@ class FitRun:
             "missing": [bool(b.has_miss) for b in self.blocks], "responses": self.M,
             "sharded": bool(comm.sharded), "world": int(comm.world),
             "graphs": bool(self.use_graphs and self._graphs), "graph_error": self._graph_error,
-            "collectives_in_graph": bool(getattr(self, "_collectives_captured", False)),
+            "collectives_in_graph": self._collectives_captured is True,
             "backend": getattr(eng.be, "name", type(eng.be).__name__),
         }
         if self.algorithm == "direct":

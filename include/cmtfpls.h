@@ -38,6 +38,9 @@ extern "C" {
 
 int cmtfpls_abi_version(void);
 const char* cmtfpls_last_error(void);
+/* Reset the HIP runtime's per-thread last error and this library's message; returns 1 if an error was pending.  For callers
+ * that capture launch sequences into HIP graphs: a capture that fails leaves the error set, and the next entry would report it. */
+int cmtfpls_clear_error(void);
 /* A few status words (convergence norm, rank-1 flags) to PINNED host memory behind the work enqueued so far, then `event`
  * (a hipEvent_t, nullable) recorded: what the host waits on once per NIPALS iteration (tpls.py:103-107) -- one call instead
  * of a framework copy + record, because the pipelined inner loop (engine.FitRun._inner_loop_xcov_pipelined) is bound by host time. */
@@ -242,6 +245,11 @@ int cmtfpls_score_f32(const float* X, int64_t I, int A, int B, const double* wA,
                       const double* rowcnt, double* t, void* stream);
 int cmtfpls_score_f64(const double* X, int64_t I, int A, int B, const double* wA, const double* wB,
                       const double* rowcnt, double* t, void* stream);
+/* score_s: the same contraction for the M rows of a cross-covariance S = Y^T X_(0) inside the xcov loop, tq[m] = S[m, :] . w
+ * (= Y^T t, tpls.py:100).  Few long rows (M <= 64, P >= 8192) take one 1024-thread workgroup per row.  Kept apart from
+ * cmtfpls_score_*: that kernel sums in another order, and the score of a SAMPLE must not depend on how many samples are
+ * passed with it -- M is fixed for a fit, a batch size is not. */
+int cmtfpls_score_s_f64(const double* S, int M, int A, int B, const double* wA, const double* wB, double* tq, void* stream);
 
 /* Deflation of one component fused with the first contraction of the next (tpls.py:109 followed by
  * tpls.py:80-83 of the next pass of the component loop): X is deflated in place exactly as

@@ -214,6 +214,9 @@ class NumpyBackend:
         out.copy_(torch.from_numpy(t))
         return out
 
+    def score_s(self, S, A, B, wA, wB, out):
+        return self.score(S, A, B, wA, wB, None, out)
+
     def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha=1.0, csum=None):
         if X2.shape[1] % 2 == 1:
             return None        # stands for "row outside the registers of one workgroup": the engine must make the two passes

@@ -59,93 +59,9 @@ def check_fit(m, fit, block=0, rtol=RTOL):
     assert all(abs(a - b) <= 1 for a, b in zip(m.n_iter_, fit.n_iter))
 
 
-# ---- (4096, 128, 128), M = 16: BASELINE configs[1] with 1/16 of the rows -----------------------------
-@pytest.fixture(scope="module")
-def cfg2_replica():
-    x, y, cp = O.import_synthetic((4096, 128, 128), 16, 10, error=0.1, seed=215)
-    x, y = _f32(x), _f32(y)
-    return x, y, cp, O.fit_tpls(x, y, 3, max_iter=25)
-
-
-@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
-def test_cfg2_replica_fit_vs_oracle(api, cfg2_replica, algorithm):
-    x, y, _, fit = cfg2_replica
-    m = api.tPLS(3, dtype="float32", algorithm=algorithm)
-    m.fit(x, y, max_iter=25)
-    check_fit(m, fit)
-    # transform / predict at this shape: one-pass MTTKRP and, with a NaN planted, the sequential score_deflate path
-    T = m.transform(x[:512])
-    col_close(T, O.transform(fit, x[:512]))
-    xt = x[:256].copy()
-    xt[3, 5, 7] = np.nan
-    col_close(m.transform(xt), O.transform(fit, xt))
-    assert_allclose(m.predict(x[:512]), O.predict(fit, x[:512]), rtol=1e-5, atol=1e-5 * np.abs(y).max())
-
-
-def test_cfg2_replica_graph_replay(api, cfg2_replica):
-    x, y, _, fit = cfg2_replica
-    g = api.tPLS(3, dtype="float32", graphs=True)
-    g.fit(x, y, max_iter=25)
-    check_fit(g, fit)
-
-
-# ---- (1024, 256, 256), M = 32: BASELINE configs[4] with 1/256 of the rows ----------------------------
-@pytest.fixture(scope="module")
-def cfg5_replica():
-    x, y, _ = O.import_synthetic((1024, 256, 256), 32, 10, error=0.1, seed=215)
-    x, y = _f32(x), _f32(y)
-    return x, y, O.fit_tpls(x, y, 3, max_iter=20)
-
-
-@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
-def test_cfg5_replica_fit_vs_oracle(api, cfg5_replica, algorithm):
-    x, y, fit = cfg5_replica
-    m = api.tPLS(3, dtype="float32", algorithm=algorithm)
-    m.fit(x, y, max_iter=20)
-    check_fit(m, fit)
-    col_close(m.transform(x[:256]), O.transform(fit, x[:256]))
-    xt = x[:64].copy()
-    xt[1, 2, 3] = np.nan                                         # sequential path: score_deflate with the parked half row
-    col_close(m.transform(xt), O.transform(fit, xt))
-
-
-# ---- coupled: tensor (1024, 128, 128) + matrix (1024, 512) sharing the sample mode (configs[2]) -----------
-@pytest.fixture(scope="module")
-def cfg3_replica():
-    x, y, cp = O.import_synthetic((1024, 128, 128), 16, 10, error=0.1, seed=215)
-    xm = cp.factors[0] @ np.random.default_rng(216).normal(size=(512, 10)).T + 0.1 * np.random.default_rng(5).normal(size=(1024, 512))
-    x, xm, y = _f32(x), _f32(xm), _f32(y)
-    return x, xm, y, O.fit_ctpls([x, xm], y, 3, max_iter=25)
-
-
-@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
-def test_cfg3_replica_coupled_vs_oracle(api, cfg3_replica, algorithm):
-    x, xm, y, fit = cfg3_replica
-    m = api.ctPLS(3, dtype="float32", algorithm=algorithm)
-    m.fit([x, xm], y, max_iter=25)
-    check_fit(m, fit, block=0)
-    check_fit(m, fit, block=1)
-    col_close(m.transform([x[:256], xm[:256]]), O.transform(fit, [x[:256], xm[:256]]))
-
-
-# ---- 30 % NaN at 128 x 128 (configs[3]) ----------------------------------------------------------------
-@pytest.fixture(scope="module")
-def cfg4_replica():
-    x, y, _ = O.import_synthetic((1024, 128, 128), 16, 10, error=0.1, seed=215)
-    x, y = _f32(x), _f32(y)
-    x[np.random.default_rng(217).random(x.shape) < 0.3] = np.nan
-    return x, y, O.fit_tpls(x, y, 3, max_iter=25)
-
-
-@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
-def test_cfg4_replica_nan30_vs_oracle(api, cfg4_replica, algorithm):
-    x, y, fit = cfg4_replica
-    m = api.tPLS(3, dtype="float32", algorithm=algorithm)
-    m.fit(x, y, max_iter=25)
-    assert m.X_hasMiss
-    check_fit(m, fit)
-    col_close(m.transform(x[:256]), O.transform(fit, x[:256]))
-
+# The R = 3 replicas of BASELINE configs[1..4] that lived here (round 2) repeated tests/test_gpu_r10_parity.py's inputs with a
+# smaller rank and their own CPU oracle fits (~55 s of the suite); their extra assertions -- transform with a planted NaN,
+# predict, float32 graph replay -- moved onto the R = 10 fits there (round 4).
 
 # ---- BASELINE configs[4] at FULL size on one GPU through size-independent properties ---------------------
 def test_cfg5_full_size_properties(api):
@@ -181,6 +97,17 @@ def test_cfg5_full_size_properties(api):
 
 
 # ---- trailing modes beyond every BASELINE config: rows of 196 608 - 655 360 elements -----------------
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def _long_rows_oracle(shape, M, dt):
+    x, y, _ = O.import_synthetic(shape, M, 3, error=0.1, seed=31)
+    if dt == "float32":
+        x, y = _f32(x), _f32(y)
+    return O.fit_tpls(x, y, 2, max_iter=8)
+
+
 @pytest.mark.parametrize("shape,M,dt", [((48, 512, 384), 5, "float32"), ((24, 1024, 640), 3, "float64")])
 @pytest.mark.parametrize("algorithm", ["direct", "xcov"])
 def test_very_long_rows_fit_vs_oracle(api, shape, M, dt, algorithm):
@@ -192,9 +119,9 @@ def test_very_long_rows_fit_vs_oracle(api, shape, M, dt, algorithm):
     x, y, _ = O.import_synthetic(shape, M, 3, error=0.1, seed=31)
     if dt == "float32":
         x, y = _f32(x), _f32(y)
-    fit = O.fit_tpls(x, y, 2, max_iter=25)
+    fit = _long_rows_oracle(shape, M, dt)                        # max_iter = 8: parity at a fixed iteration count is as strict
     m = api.tPLS(2, dtype=dt, algorithm=algorithm)
-    m.fit(x, y, max_iter=25)
+    m.fit(x, y, max_iter=8)
     check_fit(m, fit, rtol=RTOL if dt == "float32" else 1e-7)
     T = m.transform(x[:16])
     col_close(T, O.transform(fit, x[:16]), RTOL if dt == "float32" else 1e-7)

@@ -135,8 +135,8 @@ def _full_size_case(api, title, coupled, data, Y):
     for f in loads:
         np.testing.assert_allclose(norm(f, axis=0), 1, rtol=1e-12)
     assert np.all(np.diff(direct.R2Y) >= -1e-12)
-    for r in (direct.R2Xs if coupled else [direct.R2X]):
-        assert np.all(np.diff(r) >= -1e-12)
+    if not coupled:                                    # (a coupled fit's R2Xs need not increase -- tests/test_cmtf.py:27,39 -- nor be positive)
+        assert np.all(np.diff(direct.R2X) >= -1e-12)
     s = np.abs(T).max()
     np.testing.assert_allclose(direct.transform(data), T, rtol=1e-4, atol=1e-5 * s)
     return direct, xcov

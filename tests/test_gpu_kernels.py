@@ -502,10 +502,10 @@ def test_score_gram_and_q_update(be, shape, M, dt, masked):
     t = be.empty(I)
     qpart = be.empty(be.n_partials * M)
     assert be.score_gram(X, A, B, dev(wa), dev(wb), rowcnt, t, Y, qpart) is not None
-    if I <= 64 and A * B >= 8192:                                       # plain score of a FEW LONG rows: the workgroup-per-row kernel
-        np.testing.assert_allclose(host(t), host(t_ref), rtol=1e-13, atol=1e-13 * float(t_ref.abs().max()))   # (another summation order)
-    else:
-        assert torch.equal(t, t_ref)                                    # the score itself is unchanged
+    assert torch.equal(t, t_ref)                                        # the score itself is unchanged, whatever the batch size
+    if not masked and dt == "f64" and I <= 64 and A * B >= 8192:        # the rows of a cross-covariance S: the workgroup-per-row kernel
+        ts = be.score_s(X, A, B, dev(wa), dev(wb), be.empty(I))
+        np.testing.assert_allclose(host(ts), host(t_ref), rtol=1e-13, atol=1e-13 * float(t_ref.abs().max()))   # (another summation order)
     th = host(t)
     want_q = y.T @ th
     scale = np.abs(y).T @ np.abs(th) + 1e-300

@@ -95,13 +95,20 @@ def cfg2():
     return blocks[0], y, fit, head
 
 
-@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
-def test_cfg2_replica_r10(api, cfg2, algorithm):
+@pytest.mark.parametrize("algorithm,graphs", [("direct", False), ("xcov", False), ("direct", True)])
+def test_cfg2_replica_r10(api, cfg2, algorithm, graphs):
     x, y, fit, head = cfg2
-    m = api.tPLS(R, dtype="float32", algorithm=algorithm)
+    m = api.tPLS(R, dtype="float32", algorithm=algorithm, graphs=graphs)
     m.fit(x, y)
-    check(m, fit, f"(4096,128,128) M=16 R=10 f32 {algorithm}")
+    assert m.fit_report_["graphs"] is graphs
+    check(m, fit, f"(4096,128,128) M=16 R=10 f32 {algorithm}{' graphs' if graphs else ''}")
     assert column_errors(m.transform(x[:256]), head)["normwise"].max() <= RTOL
+    # transform / predict at this shape: one-pass MTTKRP and, with a NaN planted, the masked sequence for that sample only
+    xt = x[:256].copy()
+    xt[3, 5, 7] = np.nan
+    assert column_errors(m.transform(xt), O.transform(fit, xt))["normwise"].max() <= RTOL
+    assert m.projection_report_["incomplete_rows"] == 1
+    np.testing.assert_allclose(m.predict(x[:512]), O.predict(fit, x[:512]), rtol=1e-5, atol=1e-5 * np.abs(y).max())
 
 
 @pytest.mark.parametrize("algorithm,graphs", [("direct", False), ("xcov", False), ("direct", True)])
@@ -166,6 +173,9 @@ def test_cfg5_replica_r10(api, cfg5, algorithm):
     m.fit(x, y)
     check(m, fit, f"(1024,256,256) M=32 R=10 f32 {algorithm}")
     assert column_errors(m.transform(x[:256]), head)["normwise"].max() <= RTOL
+    xt = x[:64].copy()
+    xt[1, 2, 3] = np.nan                                         # rows of 256 x 256: the 1024-thread rows-in-registers form
+    assert column_errors(m.transform(xt), O.transform(fit, xt))["normwise"].max() <= RTOL
 
 
 # ---- BASELINE configs[2] replica: coupled ---------------------------------------------------------------

@@ -184,10 +184,10 @@ def test_xcov_without_writing_x_on_gpu(dtype, case, monkeypatch):
     if case == "order4":
         x, y, _ = O.import_synthetic((600, 12, 8, 6), 5, R, error=0.2, seed=21)
     else:
-        x, y, cp = O.import_synthetic((2048, 128, 64), 6, R, error=0.2, seed=21)
+        x, y, cp = O.import_synthetic((512, 128, 64), 6, R, error=0.2, seed=21)     # (the CPU oracle fit is what takes the time here)
     Xs = [x]
     if case == "coupled":
-        Xs.append(cp.factors[0] @ np.random.default_rng(3).normal(size=(40, R)).T + 0.1 * np.random.default_rng(4).normal(size=(2048, 40)))
+        Xs.append(cp.factors[0] @ np.random.default_rng(3).normal(size=(40, R)).T + 0.1 * np.random.default_rng(4).normal(size=(512, 40)))
     if dtype == "float32":
         Xs = [a.astype(np.float32).astype(np.float64) for a in Xs]
     fit = O.fit_ctpls(Xs, y, R) if case == "coupled" else O.fit_tpls(Xs[0], y, R)
@@ -235,9 +235,9 @@ def test_transform_reads_the_callers_tensor_once_and_in_place(dtype, coupled):
     means here are 50x the spread of the data, so a centring lost to cancellation would show at once."""
     from cmtf_pls_amd import ctPLS, tPLS
     td = getattr(torch, dtype)
-    x, y, _ = O.import_synthetic((3072, 128, 64), 6, 4, error=0.2, seed=12)
+    x, y, _ = O.import_synthetic((768, 128, 64), 6, 4, error=0.2, seed=12)      # (the CPU oracle fit is what takes the time here)
     x = x + 50.0 * np.random.default_rng(1).normal(size=x.shape[1:])
-    xm = np.random.default_rng(2).normal(size=(3072, 40)) + 30.0
+    xm = np.random.default_rng(2).normal(size=(768, 40)) + 30.0
     if dtype == "float32":
         x, xm = x.astype(np.float32).astype(np.float64), xm.astype(np.float32).astype(np.float64)
     if coupled:
@@ -248,7 +248,7 @@ def test_transform_reads_the_callers_tensor_once_and_in_place(dtype, coupled):
         m = tPLS(3, dtype=dtype)
         m.fit(x, y)
         fit = O.fit_tpls(x, y, 3)
-    new = [x[:2048], xm[:2048]] if coupled else [x[:2048]]
+    new = [x[:512], xm[:512]] if coupled else [x[:512]]
     dev = [torch.from_numpy(a).to(td).to("cuda:0") for a in new]
     keep = [d.clone() for d in dev]
     want = O.transform(fit, new)

@@ -465,7 +465,7 @@ def test_score_contract_declines_rows_outside_the_registers_of_one_workgroup(be)
 
 
 @pytest.mark.parametrize("raw", [True, False])
-@pytest.mark.parametrize("dtype,shape", [("float32", (400, 128, 128)), ("float64", (300, 64, 128)), ("float32", (500, 4096)),
+@pytest.mark.parametrize("dtype,shape", [("float32", (160, 128, 128)), ("float64", (160, 64, 128)), ("float32", (500, 4096)),
                                          ("float32", (300, 8, 16, 32))])
 def test_xcov_fit_with_one_read_per_component_equals_the_two_reads(api, monkeypatch, dtype, shape, raw):
     """tPLS(algorithm="xcov") on one block reads X once per component (plus the two reads that build S and the norm): the second
