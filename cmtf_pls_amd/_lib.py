@@ -110,6 +110,8 @@ SIGNATURES = {
     "cmtfpls_recon_r2_f64": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_loo_fold_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cmtfpls_loo_tpls_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_loo_xcov_fold_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cmtfpls_loo_xcov_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_fit_small_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cmtfpls_fit_small_f64": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_int] + [_P] * 11 + [_P, c_size_t, _P]),
     "cmtfpls_add_noise_f32": (c_int, [_P, c_int64, c_double, c_uint64, c_uint64, c_double, _P]),

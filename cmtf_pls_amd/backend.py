@@ -562,27 +562,49 @@ class HipBackend:
         return out
 
     def loo_tpls(self, X2: torch.Tensor, Y: torch.Tensor, A: int, B: int, R: int, tol: float, max_iter: int,
-                 max_ws_bytes: int = 4 << 30) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+                 max_ws_bytes: Optional[int] = None, forms=("lds", "xcov")) -> Optional[Tuple[torch.Tensor, torch.Tensor, str]]:
         """Leave-one-out predictions of a tPLS model (validate.py:24-33), every fold a workgroup: returns
-        (Ypred (I, M), n_iter (I, R)) or None when the shape is outside the one-workgroup-per-fold form."""
+        (Ypred (I, M), n_iter (I, R), form) or None when the shape is outside both workgroup-per-fold forms.  form:
+        "lds" = cmtfpls_loo_tpls_f64 (the fold's vectors in LDS: min(A, B) <= 64), "xcov" = cmtfpls_loo_xcov_f64 (the fold's loop on
+        its cross-covariance, Gram squarings on the matrix cores: min(A, B) <= 256).  Folds run in chunks that fit `max_ws_bytes`
+        (default: a third of the free HBM) -- the xcov form keeps a centred copy of X per resident fold."""
         I, P = X2.shape
         M = Y.shape[1]
         assert X2.dtype == torch.float64 and Y.dtype == torch.float64 and X2.is_contiguous() and Y.is_contiguous() and P == A * B
-        per = self.lib.cmtfpls_loo_fold_workspace_bytes(I, A, B, M, R)
-        chunk = max(1, min(I, int(max_ws_bytes // max(per, 1))))
-        ws = self._workspace("loo", per * chunk)
         colsum_x, _ = self.colstats(X2)
         colsum_y, _ = self.colstats(Y)
         Ypred = self.empty(I, M)
         n_iter = torch.zeros(I, R, dtype=torch.int32, device=self.device)
-        for f0 in range(0, I, chunk):
-            nf = min(chunk, I - f0)
-            rc = self.lib.cmtfpls_loo_tpls_f64(_ptr(X2), _ptr(Y), _ptr(colsum_x), _ptr(colsum_y), I, A, B, M, R, float(tol), int(max_iter),
-                                               f0, nf, _ptr(Ypred), _ptr(n_iter), _ptr(ws), ws.numel(), self._stream())
-            if rc == 4:
-                return None
-            _lib.check(rc, "loo_tpls")
-        return Ypred, n_iter
+        for form, per_fn, fn in (("lds", self.lib.cmtfpls_loo_fold_workspace_bytes, self.lib.cmtfpls_loo_tpls_f64),
+                                 ("xcov", self.lib.cmtfpls_loo_xcov_fold_workspace_bytes, self.lib.cmtfpls_loo_xcov_f64)):
+            if form not in forms:
+                continue
+            # probe without a workspace: the shape check comes first (status 4 = this form declines, 2 = it only misses the workspace)
+            if fn(_ptr(X2), _ptr(Y), _ptr(colsum_x), _ptr(colsum_y), I, A, B, M, R, float(tol), int(max_iter), 0, 1, _ptr(Ypred),
+                  _ptr(n_iter), None, 0, self._stream()) == 4:
+                continue
+            per = per_fn(I, A, B, M, R)
+            budget = max_ws_bytes
+            if budget is None:
+                budget = (4 << 30) if form == "lds" else max(4 << 30, torch.cuda.mem_get_info(self.device)[0] // 3)
+            chunk = max(1, min(I, int(budget // max(per, 1))))
+            if form == "xcov":
+                chunk = min(chunk, 512)                      # two workgroups' worth of folds per CU is all a launch can overlap
+            declined = False
+            ws = None
+            for f0 in range(0, I, chunk):
+                nf = min(chunk, I - f0)
+                if ws is None:
+                    ws = self._workspace("loo", per * min(chunk, I))
+                rc = fn(_ptr(X2), _ptr(Y), _ptr(colsum_x), _ptr(colsum_y), I, A, B, M, R, float(tol), int(max_iter),
+                        f0, nf, _ptr(Ypred), _ptr(n_iter), _ptr(ws), ws.numel(), self._stream())
+                if rc == 4:
+                    declined = True
+                    break
+                _lib.check(rc, "loo_" + form)
+            if not declined:
+                return Ypred, n_iter, form
+        return None
 
     def fit_small(self, X2: torch.Tensor, Y: torch.Tensor, A: int, B: int, R: int, tol: float, max_iter: int):
         """The complete tPLS.fit of a small float64 problem without missing values in ONE launch (cmtfpls_fit_small_f64):

@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function)
 objs=()
 pids=()
-for src in runtime sweeps small rank1 rank1_tensor xcov mttkrp mixed ceiling solve recon synth loo collective project scorecontract; do
+for src in runtime sweeps small rank1 rank1_tensor xcov mttkrp mixed ceiling solve recon synth loo loo_xcov collective project scorecontract; do
   "$HIPCC" "${FLAGS[@]}" -c "$HERE/$src.hip" -o "$OUT/$src.o" &
   pids+=($!)
   objs+=("$OUT/$src.o")

@@ -2,10 +2,12 @@
 
 The reference reads ``pls_tensor.original_X / original_Y``, which its own ``tPLS.fit`` never stores
 (they are locals at tpls.py:74), so ``get_q2y`` fails there on any fitted model; the estimator here
-keeps them.  One refit per held-out sample (validate.py:27-33).  On the GPU all folds run in ONE launch
-(``cmtfpls_loo_tpls_f64``: a workgroup per fold does the whole fit for it, fold means down-dated from shared column
-sums) when X has order 2 or 3, no missing values and the per-fold vectors fit the LDS; otherwise every refit runs
-on the regular engine with the fitted model's storage type, algorithm and backend.
+keeps them.  One refit per held-out sample (validate.py:27-33).  On the GPU the folds run side by side, a workgroup per
+fold doing the whole fit for it with the fold's means down-dated from shared column sums: ``cmtfpls_loo_tpls_f64`` when the
+fold's vectors fit the LDS (min(J, K) <= 64), ``cmtfpls_loo_xcov_f64`` beyond (min(J, K) <= 256: the fold's NIPALS loop on its
+cross-covariance, Gram squarings on the matrix cores) -- X of order 2 or 3 without missing values, M <= 64, R <= 16.  Anything else
+refits once per fold on the regular engine with the fitted model's storage type, algorithm and backend.  Which form ran is
+recorded on the model (``q2y_report_``).
 """
 import numpy as np
 
@@ -34,6 +36,9 @@ def loo_predictions(pls_tensor, tol: float = 1e-8, max_iter: int = 100):
         out = be.loo_tpls(Xd, Yd, A, B, pls_tensor.n_components, tol, max_iter)
         if out is None:
             return None
+        pls_tensor.q2y_report_ = {"form": {"lds": "all folds in one launch, a workgroup per fold, vectors in LDS (cmtfpls_loo_tpls_f64)",
+                                           "xcov": "a workgroup per fold on the fold's cross-covariance (cmtfpls_loo_xcov_f64)"}[out[2]],
+                                  "folds": int(I), "n_iter_total": int(out[1].sum().item())}
         return out[0].cpu().numpy().reshape(Yh.shape)
 
 
@@ -45,6 +50,9 @@ def get_q2y(pls_tensor, device_folds: bool = True):
     Y_pred = loo_predictions(pls_tensor) if device_folds else None
     Y_actual = Y.astype(float)
     if Y_pred is None:
+        why = ("device folds switched off" if not device_folds else
+               "order > 3, missing values, min(J, K) > 256, M > 64 or R > 16: outside both workgroup-per-fold kernels")
+        pls_tensor.q2y_report_ = {"form": "one refit per fold on the regular engine", "folds": int(n), "why": why}
         refit = tPLS(pls_tensor.n_components, dtype=pls_tensor._dtype, device=pls_tensor._device,
                      backend=pls_tensor._backend, algorithm=pls_tensor._algorithm)
         Y_pred = np.zeros(Y.shape)

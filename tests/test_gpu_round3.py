@@ -751,7 +751,7 @@ def test_rank1_score_equals_rank1_then_score_bit_for_bit(be, A, B, M):
     Z = _dev(z.reshape(-1))
     w1, v1, i1, t1 = be.empty(A), be.empty(B), be.zeros(2), be.empty(M)
     be.rank1(Z, A, B, w1, v1, info=i1)
-    be.score(S, A, B, w1, v1, None, t1)
+    be.score_s(S, A, B, w1, v1, t1)                              # (the score of the M rows of S: cmtfpls_score_s_f64)
     w2, v2, i2, t2 = be.empty(A), be.empty(B), be.zeros(2), be.empty(M)
     be.rank1_score(Z, A, B, w2, v2, S, t2, info=i2)
     assert torch.equal(w1, w2) and torch.equal(v1, v2) and torch.equal(i1, i2) and torch.equal(t1, t2)
