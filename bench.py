@@ -9,7 +9,7 @@ it is one rank; WORLD_SIZE != --gpus is refused with a non-zero exit before any 
 group is checked to have exactly N ranks.
 
 A *step* is ONE direct-form NIPALS inner iteration of the product engine
-(cmtf_pls_amd.engine.FitRun.iterate = reference tpls.py:80-107): mode-0 contraction (one read of X),
+(cmtf_pls_amd.fitrun.FitRun.iterate = reference tpls.py:80-107): mode-0 contraction (one read of X),
 rank-1 extraction, score contraction (second read of X), Y update, convergence norm read back to the
 host exactly as the reference tests it every iteration.  Inputs are resident in HBM before the timed
 region.  Workload: BASELINE.json configs[1] (X 65536x128x128 f32, Y 65536x16, R=10), STRONG scaling:
@@ -548,7 +548,7 @@ def main():
                             "iters_per_sec_in_fit": sum(sx.n_iter) / xs,
                             "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
                             "max_abs_dT_vs_direct": float((sx.T - st.T).abs().max())}
-        # which forms ran (engine.FitRun.build_report): algorithm after fallbacks, passes over X, centred copy or the caller's
+        # which forms ran (fitrun.FitRun.build_report): algorithm after fallbacks, passes over X, centred copy or the caller's
         # tensor, pipelined, graph replay -- and every fast form the shape declined, in words
         fit_info["path"] = {"direct": st.report, "xcov": sx.report}
         # opt-in mixed precision of the S build (f32 MFMA, csrc/mixed.hip): reported, never the headline

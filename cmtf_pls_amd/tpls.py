@@ -114,7 +114,7 @@ class _EstimatorBase(Mapping):
 
     @property
     def fit_report_(self) -> dict:
-        """Which form of every step the last fit took (engine.FitRun.build_report)."""
+        """Which form of every step the last fit took (fitrun.FitRun.build_report)."""
         return dict(self._state.report)
 
     @property

@@ -93,6 +93,24 @@ def test_order4_components_satisfy_the_rank1_stationarity_conditions(api, algori
     _record(f"order-4 X (512,24,20,16) R=4 f64 {algorithm}: stationarity of the rank-1 CP + one pass of the loop", recs)
 
 
+@pytest.mark.parametrize("algorithm", ["direct", "xcov"])
+def test_coupled_blocks_of_mixed_orders_with_missing_values(api, algorithm):
+    """ctPLS on an order-4 block, an order-3 block with 20 % NaN and a matrix (cmtf.py:92-123: per-block contraction -- masked
+    where the block has missing values -- rank-1 CP or Z / |Z|, per-block scores, np.average): every converged component against
+    one pass of that loop."""
+    rng = np.random.default_rng(51)
+    lat = rng.normal(size=(400, 4))
+    x4 = np.einsum("ir,jr,kr,lr->ijkl", lat, rng.normal(size=(12, 4)), rng.normal(size=(10, 4)), rng.normal(size=(8, 4))) + 0.1 * rng.normal(size=(400, 12, 10, 8))
+    x3 = np.einsum("ir,jr,kr->ijk", lat, rng.normal(size=(16, 4)), rng.normal(size=(32, 4))) + 0.1 * rng.normal(size=(400, 16, 32))
+    x3[rng.random(x3.shape) < 0.2] = np.nan
+    xm = lat @ rng.normal(size=(4, 40)) + 0.1 * rng.normal(size=(400, 40))
+    y = lat @ rng.normal(size=(4, 5)) + 0.1 * rng.normal(size=(400, 5))
+    m = api.ctPLS(4, dtype="float64", algorithm=algorithm)
+    m.fit([x4, x3, xm], y)
+    recs = check_estimator(m, [x4, x3, xm], y, device="cuda", rtol=1e-6, min_checked=3, stationarity_rtol=1e-4, label=f"mixed orders {algorithm}")
+    _record(f"coupled (400,12,10,8) + (400,16,32) 20% NaN + (400,40) R=4 f64 {algorithm}: one pass of cmtf.py:92-123 (torch f64)", recs)
+
+
 # ---- (b) + (c) full size -------------------------------------------------------------------------------------------
 def _full(matrix_block=0, nan_fraction=0.0):
     from cmtf_pls_amd.synthetic import synthetic_shard_device

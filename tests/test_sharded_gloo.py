@@ -38,7 +38,7 @@ def _worker(rank, world, port, case, ret):
         from cmtf_pls_amd.engine import Comm
         from numpy_backend import NumpyBackend
 
-        x, y, cp = O.import_synthetic((60, 8, 6), 3, 3, error=0.1, seed=21)
+        x, y, cp = O.import_synthetic((60, 8, 6), 70 if case.endswith("_m70") else 3, 3, error=0.1, seed=21)   # _m70: more responses than one S tile
         if case in ("nan", "xcov_nan"):
             x[np.random.default_rng(3).random(x.shape) < 0.25] = np.nan
         if case == "xcov_raw":
@@ -81,7 +81,7 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["plain", "nan", "coupled", "xcov", "xcov_nan", "xcov_coupled", "xcov_raw"])
+@pytest.mark.parametrize("case", ["plain", "nan", "coupled", "xcov", "xcov_nan", "xcov_coupled", "xcov_raw", "xcov_m70", "plain_m70"])
 def test_world2_matches_oracle(case):
     world = 2
     with mp.Manager() as mgr:

@@ -129,7 +129,7 @@ for case in range(n_proj):
     dtype = "float32" if f32 else "float64"
     m = (ctPLS if coupled else tPLS)(R, dtype=dtype, options=REG)
     m.fit(blocks if coupled else blocks[0], y, max_iter=15)
-    n_new = int(rng.integers(1, 40))
+    n_new = min(I, int(rng.integers(1, 40)))
     new = [b[:n_new].copy() for b in blocks]
     frac = float(rng.choice([0.0, 0.1, 0.5, 1.0]))
     bad = rng.random(n_new) < frac
