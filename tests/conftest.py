@@ -35,8 +35,10 @@ def _regular_engine_unless_asked(request):
     reference's own suite, the configs[0] golden tests in both modes (`small_fit_mode`) -- see the product default; tests of
     one switch construct their own `EngineOptions(...)` and pass it to the estimator."""
     from cmtf_pls_amd.engine import EngineOptions, set_default_options
-    keep = request.node.get_closest_marker("small_fit") is not None
-    old = set_default_options(EngineOptions() if keep else EngineOptions(small_fit=False))
+    if request.node.get_closest_marker("small_fit") is not None:
+        yield                                # the process default as it stands (the product's, unless a module fixture runs both modes)
+        return
+    old = set_default_options(EngineOptions(small_fit=False))
     yield
     set_default_options(old)
 

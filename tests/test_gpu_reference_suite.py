@@ -11,11 +11,21 @@ import pytest
 from numpy.linalg import norm
 from numpy.testing import assert_allclose
 
-pytestmark = [pytest.mark.gpu, pytest.mark.small_fit]      # the product's default behaviour, small fits included
+pytestmark = [pytest.mark.gpu, pytest.mark.small_fit]      # the product's default behaviour, small fits included ...
 
 TENSOR_DIMENSIONS = (100, 38, 65)      # tests/test_tpls.py:13-15, tests/test_synthetic.py:4-6
 N_RESPONSE = 4
 N_LATENT = 8
+
+
+@pytest.fixture(scope="module", params=["product_default", "regular_engine"], autouse=True)
+def engine_mode(request):
+    """... and the whole suite a second time on the multi-launch engine (a small float64 fit takes the one-launch kernel
+    by default, which most other suites switch off): the drop-in claim must hold on both paths."""
+    from cmtf_pls_amd.engine import EngineOptions, set_default_options
+    old = set_default_options(EngineOptions(small_fit=(request.param == "product_default")))
+    yield request.param
+    set_default_options(old)
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +38,7 @@ def pkg():
 
 
 @pytest.fixture(scope="module")
-def standard(pkg):                                             # tests/test_tpls.py:21-25
+def standard(pkg, engine_mode):                                # tests/test_tpls.py:21-25
     x, y, cp_tensor = pkg["import_synthetic"](TENSOR_DIMENSIONS, N_RESPONSE, N_LATENT)
     pls = pkg["tPLS"](N_LATENT)
     pls.fit(x, y)

@@ -142,6 +142,9 @@ def test_xcov_kernel_response_tiles_equal_one_gemm(api):
             Sm = be.xcov(Xn, Y, True)
             wantm = Y.T @ torch.nan_to_num(Xn.double(), nan=0.0)
             assert float((Sm - wantm).abs().max()) <= 1e-11 * float(wantm.abs().max()) + 1e-12, (dtype, M)
+            if dtype == torch.float32:                                   # the opt-in f32-MFMA form takes the same tiles
+                Sx = be.xcov(X, Y, False, mixed=True)
+                assert float((Sx - want).abs().max()) <= 2e-5 * float(want.abs().max()), (M, "mixed")
 
 
 # ---- projection: per-sample form ---------------------------------------------------------------------------------------------
