@@ -18,14 +18,14 @@
 //    (v_mfma_f64_16x16x4_f64, operands straight from L2 in the MFMA layout, the 16 wavefronts of the workgroup dealing the
 //    lower-triangular 16 x 16 tiles among themselves), one exact pass with Z, sign rule on the last mode.
 // Arithmetic: float64 throughout, the reference's operation order outside the re-association above.
-// Limits: X of order 2 or 3 without missing values, min(A, B) <= 256, M <= 64, R <= 16, the loadings of all components in
-// 150 KB of LDS; per resident fold a workspace of I P + M P + 2 P + 2 n^2 + I (M + R + 2) doubles (cmtfpls_loo_xcov_fold_workspace_bytes).
+// Limits: X of order 2 or 3 without missing values, min(A, B) <= 256, M <= 64, R <= 64, the workgroup's small vectors in
+// 150 KB of LDS; per resident fold a workspace of I P + M P + 3 P + 2 n^2 + I (M + R + 2) + R (A + B) doubles (cmtfpls_loo_xcov_fold_workspace_bytes).
 #include "common.hpp"
 
 namespace cmtfpls {
 
 constexpr int kLxNT = 1024, kLxWaves = kLxNT / 64;
-constexpr int kLxMaxN = 256, kLxMaxM = 64, kLxMaxR = 16;
+constexpr int kLxMaxN = 256, kLxMaxM = 64, kLxMaxR = 64;
 
 typedef double lx_d4_t __attribute__((ext_vector_type(4)));
 
@@ -202,6 +202,22 @@ __device__ void lx_rank1(const double* Z, double* Zt, int A, int B, double* wA, 
   __syncthreads();
 }
 
+// sum_c row[c] * wk[c] over one wavefront's columns c = lane, lane + 64, ...: one fma chain per lane in column order (the order of the
+// plain loop), eight loads of each operand in flight per trip
+__device__ __forceinline__ double lx_wave_dot(const double* row, const double* wk, int64_t P, int lane) {
+  double s = 0.0;
+  int64_t c = lane;
+  for (; c + 7 * 64 < P; c += 8 * 64) {
+    double xv[8], wv8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xv[j] = row[c + 64 * j]; wv8[j] = wk[c + 64 * j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fma(xv[j], wv8[j], s);
+  }
+  for (; c < P; c += 64) s = fma(row[c], wk[c], s);
+  return wave_sum(s);
+}
+
 __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
   extern __shared__ double sm[];
   __shared__ double red[kLxWaves];
@@ -222,10 +238,13 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
   double* S = T + (int64_t)I * R;                            // M x P   cross-covariance of the current component
   double* Z = S + (int64_t)M * P;                            // P
   double* Zt = Z + P;                                        // P       (transpose scratch of the rank-1 extraction)
-  double* G0 = Zt + P;                                       // n x n
+  double* wk = Zt + P;                                       // P       kron(wA, wB) of the current loadings
+  double* G0 = wk + P;                                       // n x n
   double* G1 = G0 + (int64_t)n * n;
   double* u = G1 + (int64_t)n * n;                           // I
   double* t = u + I;                                         // I
+  double* Wa = t + I;                                        // R x A   loadings of the components so far (read again by the prediction only)
+  double* Wb = Wa + (int64_t)R * A;                          // R x B
   // LDS carve-up
   double* wA = sm;
   double* wB = wA + A;
@@ -237,9 +256,7 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
   double* xs = Gy + M * M;        // n
   double* ys = xs + n;            // k
   double* coef = ys + k;          // R x R
-  double* Wa = coef + R * R;      // R x A
-  double* Wb = Wa + R * A;        // R x B
-  double* Qs = Wb + R * B;        // R x M
+  double* Qs = coef + R * R;      // R x M
   double* Gn = Qs + R * M;        // (a+1) x (a+1) normal equations
   double* gn = Gn + R * R;
   double* bb = gn + R;
@@ -270,7 +287,22 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
         double acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-        for (int r = 0; r < I; ++r) {
+        // four rows of the column in flight at a time (one row per trip leaves a single load per lane outstanding: the pass
+        // is then bound by memory latency, 16 ms per component and fold at 512 x 16384 instead of 2)
+        int r = 0;
+        for (; r + 4 <= I; r += 4) {
+          double x[4];
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4) x[u4] = Xf[(int64_t)(r + u4) * P + c];
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4) {
+            const double* yr = Yf + (int64_t)(r + u4) * M + mc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              if (mc + j < M) acc[j] = fma(yr[j], x[u4], acc[j]);
+          }
+        }
+        for (; r < I; ++r) {
           const double x = Xf[(int64_t)r * P + c];
           const double* yr = Yf + (int64_t)r * M + mc;
 #pragma unroll
@@ -294,7 +326,15 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
     for (; it < a.max_iter; ++it) {                                                    // tpls.py:79
       for (int64_t c = tid; c < P; c += kLxNT) {                                       // Z = X x_0 u = S^T q (tpls.py:83)
         double s = 0.0;
-        for (int m = 0; m < M; ++m) s = fma(q[m], S[(int64_t)m * P + c], s);
+        int m = 0;
+        for (; m + 4 <= M; m += 4) {                                                   // (four rows of S in flight; same order of the sum)
+          const double s0 = S[(int64_t)m * P + c], s1 = S[(int64_t)(m + 1) * P + c], s2 = S[(int64_t)(m + 2) * P + c], s3 = S[(int64_t)(m + 3) * P + c];
+          s = fma(q[m], s0, s);
+          s = fma(q[m + 1], s1, s);
+          s = fma(q[m + 2], s2, s);
+          s = fma(q[m + 3], s3, s);
+        }
+        for (; m < M; ++m) s = fma(q[m], S[(int64_t)m * P + c], s);
         Z[c] = s;
       }
       __syncthreads();
@@ -308,10 +348,10 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
       } else {
         lx_rank1(Z, Zt, A, B, wA, wB, G0, G1, xs, ys, red, bestv, besti);          // tpls.py:86-88
       }
+      for (int64_t c = tid; c < P; c += kLxNT) wk[c] = wA[c / B] * wB[c % B];          // the Kronecker loading, once per extraction
+      __syncthreads();
       for (int m = wv; m < M; m += kLxWaves) {                                         // Y^T t = S (wA (x) wB) (tpls.py:97-100)
-        double s = 0.0;
-        for (int64_t c = lane; c < P; c += 64) s = fma(S[(int64_t)m * P + c], wA[c / B] * wB[c % B], s);
-        s = wave_sum(s);
+        const double s = lx_wave_dot(S + (int64_t)m * P, wk, P, lane);
         if (lane == 0) tq[m] = s;
       }
       __syncthreads();
@@ -329,11 +369,8 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
     }
     if (a.n_iter && tid == 0) a.n_iter[(int64_t)fold * R + comp] = it;
     // ---- the component's score and Y score with the converged loadings (tpls.py:97-102) ----
-    for (int r = wv; r < I; r += kLxWaves) {
-      const double* xr = Xf + (int64_t)r * P;
-      double s = 0.0;
-      for (int64_t c = lane; c < P; c += 64) s = fma(xr[c], wA[c / B] * wB[c % B], s);
-      s = wave_sum(s);
+    for (int r = wv; r < I; r += kLxWaves) {                                             // (wk holds the converged loadings' Kronecker product)
+      const double s = lx_wave_dot(Xf + (int64_t)r * P, wk, P, lane);
       if (lane == 0) t[r] = s;
     }
     for (int r = tid; r < I; r += kLxNT) {
@@ -350,7 +387,7 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
     for (int r = 0; r < I; ++r) {
       const double tr = t[r];
       double* xr = Xf + (int64_t)r * P;
-      for (int64_t c = tid; c < P; c += kLxNT) xr[c] = fma(-tr, wA[c / B] * wB[c % B], xr[c]);
+      for (int64_t c = tid; c < P; c += kLxNT) xr[c] = fma(-tr, wk[c], xr[c]);
     }
     __syncthreads();
     // ---- inner regression b = lstsq(T[:, :k], u) (tpls.py:110-112): normal equations, equilibrated Cholesky (as loo.hip) ----
@@ -441,8 +478,7 @@ __global__ __launch_bounds__(kLxNT) void loo_xcov_kernel(LooXArgs a) {
 
 static size_t lx_lds_bytes(int A, int B, int M, int R) {
   const size_t n = (size_t)(A < B ? A : B), k = (size_t)(A < B ? B : A);
-  const size_t dbl = (size_t)A + B + 4 * (size_t)M + (size_t)M * M + n + k + (size_t)R * R + (size_t)R * (A + B) + (size_t)R * M +
-                     (size_t)R * R + 3 * (size_t)R;
+  const size_t dbl = (size_t)A + B + 4 * (size_t)M + (size_t)M * M + n + k + (size_t)R * R + (size_t)R * M + (size_t)R * R + 3 * (size_t)R;
   return dbl * sizeof(double);
 }
 
@@ -455,7 +491,7 @@ extern "C" {
 size_t cmtfpls_loo_xcov_fold_workspace_bytes(int I, int A, int B, int M, int R) {
   if (I <= 1 || A <= 0 || B <= 0 || M <= 0 || R <= 0) return 0;
   const size_t P = (size_t)A * B, n = (size_t)(A < B ? A : B);
-  return ((size_t)I * P + (size_t)I * M + (size_t)I * R + (size_t)M * P + 2 * P + 2 * n * n + 2 * (size_t)I) * sizeof(double);
+  return ((size_t)I * P + (size_t)I * M + (size_t)I * R + (size_t)M * P + 3 * P + 2 * n * n + 2 * (size_t)I + (size_t)R * ((size_t)A + B)) * sizeof(double);
 }
 
 int cmtfpls_loo_xcov_f64(const double* X, const double* Y, const double* colsum_x, const double* colsum_y, int I, int A, int B, int M,
@@ -469,7 +505,7 @@ int cmtfpls_loo_xcov_f64(const double* X, const double* Y, const double* colsum_
   const int n = A < B ? A : B;
   const size_t lds = lx_lds_bytes(A, B, M, R);
   if (n > kLxMaxN || M > kLxMaxM || R > kLxMaxR || lds > 150 * 1024 || (int64_t)A * B > (int64_t)1 << 24) {
-    set_error("loo_xcov: shape outside the workgroup-per-fold form (min(A, B) <= 256, M <= 64, R <= 16); refit per fold on the regular engine");
+    set_error("loo_xcov: shape outside the workgroup-per-fold form (min(A, B) <= 256, M <= 64, R <= 64); refit per fold on the regular engine");
     return CMTFPLS_EUNSUPPORTED;
   }
   const size_t per = cmtfpls_loo_xcov_fold_workspace_bytes(I, A, B, M, R);
