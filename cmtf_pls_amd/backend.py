@@ -345,7 +345,7 @@ class HipBackend:
     def score_contract(self, X2, A, B, wA, wB, shift, t, Z, sub_own=None, add_other=None, alpha: float = 1.0,
                        csum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """t = X w - shift - sub_own and Z = X^T c, c = alpha (t + add_other), in one read of X (cmtfpls_score_contract_*); csum[0] =
-        sum(c) when given; None when the row does not fit the registers of one workgroup (the caller then makes the two passes)."""
+        sum(c) when given; None when the row fits neither the registers of one workgroup nor those of 16 (the caller then makes the two passes)."""
         I, P = X2.shape
         if not X2.is_contiguous() or P != A * B:
             return None

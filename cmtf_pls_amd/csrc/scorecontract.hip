@@ -17,7 +17,8 @@
 // instead of a branch, which would make the compiler wait for every load).  One partial row of Z per workgroup, added in index
 // order by reduce_rows_kernel.  shift (device, nullable): X is uncentred, t = X w - mean^T w.  csum (nullable): sum_i c[i], what the
 // rank-one correction X_c^T c = X^T c - (1^T c) mean of an uncentred X needs (a 65536-element sum_kernel launch otherwise).
-// Shapes: B % V == 0, rows of at most 1024 * V * 4 (f32) / 1024 * V * 8 (f64) elements = 16384; no missing values.
+// Shapes: B % V == 0, no missing values; rows of at most 1024 * V * 4 (f32) / 1024 * V * 8 (f64) elements = 16384 in this form, up to
+// 16 x 16384 (f32) / 16 x 8192 (f64) elements in the split form further down (round 4: the north-star 256 x 256 row).
 #include "common.hpp"
 
 namespace cmtfpls {
@@ -157,6 +158,155 @@ __global__ __launch_bounds__(1024) void score_contract_rows_kernel(const T* __re
     }
 }
 
+// ---- rows LONGER than one workgroup's registers (round 4): the row split over G workgroups ------------------------------------
+// P f64 accumulators per row stream are what limits the form above (65536 of them = the whole register file of a CU).  Here a row
+// is cut into G column slabs of NV * 1024 * V elements and G workgroups with CONSECUTIVE block indices (dispatched together, one
+// workgroup per CU, grid <= CUs: co-resident) walk the same rows, each holding its own slab and its slab's accumulators.  The one
+// thing they owe each other is the row's dot product: workgroup g publishes its partial sum with ONE 8-byte agent-scope store into
+// xch[row * G + g] -- the value is its own flag (slots are preset to an all-ones pattern no sum produces), so there is no release
+// fence and no L2 write-back -- and all G workgroups add the G slots in index order LAG rows later (identical bits in every
+// partner), by which time the stores have long landed: the exchange costs no stall, only LAG + 2 row buffers of registers.
+// One barrier per row as before; wavefront 0 polls (a bounded spin: if a partner never shows up the score becomes NaN and the grid
+// still drains).  Row stream s = blockIdx.x / G walks rows s, s + S, ...; slab g = blockIdx.x % G; t and csum come from slab 0.
+constexpr unsigned long long kXchEmpty = ~0ull;
+constexpr int kSplitMaxG = 16;
+constexpr int kSplitSpinLimit = 1 << 21;
+
+template <typename T, int NV, bool KC, int LAG>
+__global__ __launch_bounds__(1024) void score_contract_split_kernel(const T* __restrict__ X, int64_t I, unsigned P, int B, int G,
+                                                                   const double* __restrict__ wA, const double* __restrict__ wB,
+                                                                   const double* __restrict__ shift, const double* __restrict__ sub_own,
+                                                                   const double* __restrict__ add_other, double alpha,
+                                                                   double* __restrict__ t, double* __restrict__ part,
+                                                                   double* __restrict__ csum_part, unsigned long long* xch) {
+  __shared__ double red[2][16];
+  __shared__ double tis[2];
+  constexpr int V = VecOf<T>::N;
+  using VT = Pack<T, V>;
+  constexpr unsigned stride = 1024u * V;
+  constexpr int NB = LAG + 2;                                 // row k + 1 arriving, row k just summed, ..., row k - LAG being accumulated
+  const int g = (int)(blockIdx.x % (unsigned)G);
+  const int64_t s = blockIdx.x / (unsigned)G, S = gridDim.x / (unsigned)G;
+  const unsigned c0 = (unsigned)g * (NV * stride) + threadIdx.x * V;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double wa[NV], wb[KC ? 1 : NV][V], acc[NV][V];
+  bool ok[NV];
+  unsigned col[NV];
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const unsigned c = c0 + n * stride;
+    ok[n] = c < P;
+    const unsigned cg = ok[n] ? c : 0;
+    col[n] = cg;                                               // a vector that does not exist reads column 0 with weight 0: in bounds
+    wa[n] = ok[n] ? wA[cg / (unsigned)B] : 0.0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      if (!KC || n == 0) wb[KC ? 0 : n][e] = wB[cg % (unsigned)B + e];
+      acc[n][e] = 0.0;
+    }
+  }
+  const double sh = shift ? shift[0] : 0.0;
+  const int64_t nrows = s < I ? (I - s + S - 1) / S : 0;      // the same for the G partners of a stream
+  VT buf[NB][NV];
+  double csum = 0.0;
+  bool dead = false;
+  int par = 0;
+  auto load = [&](VT (&b)[NV], int64_t row) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) b[n] = ld_stream(reinterpret_cast<const VT*>(X + row * (int64_t)P + col[n]));
+  };
+  if (nrows > 0) load(buf[0], s);
+  const int64_t steps = nrows > 0 ? nrows + LAG : 0;           // (a stream without rows makes no step: nothing to clamp a load to)
+  for (int64_t k0 = 0; k0 < steps; k0 += NB) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int64_t k = k0 + j;
+      if (k < steps) {                                         // (uniform)
+        const int64_t kn = k + 1 < nrows ? k + 1 : nrows - 1;  // always issued, a clamped row: the buffer it lands in is free either way
+        load(buf[(j + 1) % NB], s + kn * S);
+        if (k < nrows) {                                       // this slab's share of row k's dot product
+          double d = 0.0;
+#pragma unroll
+          for (int n = 0; n < NV; ++n) {
+            double dn = 0.0;
+#pragma unroll
+            for (int e = 0; e < V; ++e) dn = fma((double)buf[j][n].e[e], wb[KC ? 0 : n][e], dn);
+            d = fma(wa[n], dn, d);
+          }
+          d = wave_sum(d);
+          if (lane == 0) red[par][wv] = d;
+        }
+        const int64_t kc = k - LAG;                            // the row whose G partial sums were published LAG steps ago
+        if (kc >= 0 && wv == 0) {
+          const unsigned long long* slot = xch + (s + kc * S) * (int64_t)G + (lane < G ? lane : 0);
+          unsigned long long bits = kXchEmpty;
+          if (!dead) {
+            int spins = 0;
+            for (;;) {
+              bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (__all(bits != kXchEmpty)) break;
+              if (++spins > kSplitSpinLimit) { dead = true; break; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          double tot = 0.0;
+          for (int gg = 0; gg < G; ++gg) tot += __shfl(__longlong_as_double((long long)bits), gg, kWave);   // index order: same bits in every partner
+          if (dead) tot = __longlong_as_double(0x7FF8000000000000ll);
+          if (lane == 0) tis[par] = tot;
+        }
+        __syncthreads();
+        if (k < nrows) {
+          const double tot = row16_sum(red[par][lane & 15]);
+          if (threadIdx.x == 0) {
+            unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
+            if (bits == kXchEmpty) bits = 0x7FF8000000000000ull;
+            __hip_atomic_store(xch + (s + k * S) * (int64_t)G + g, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (kc >= 0) {
+          const int64_t row = s + kc * S;
+          double ti = tis[par] - sh;
+          if (sub_own) ti -= sub_own[row];
+          if (g == 0 && threadIdx.x == 0) t[row] = ti;
+          if (add_other) ti += add_other[row];
+          ti *= alpha;
+          csum += ti;
+          VT (&bc)[NV] = buf[(j + NB - LAG) % NB];
+          if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+              for (int e = 0; e < V; ++e) asm volatile("" : "+v"(bc[n].e[e]));
+          }
+#pragma unroll
+          for (int n = 0; n < NV; ++n)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[n][e] = fma(ti, (double)bc[n].e[e], acc[n][e]);
+        }
+        par ^= 1;
+      }
+    }
+  }
+  if (csum_part && g == 0 && threadIdx.x == 0) csum_part[s] = csum;
+  double* __restrict__ prow = part + s * (int64_t)P;
+#pragma unroll
+  for (int n = 0; n < NV; ++n)
+    if (ok[n]) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) prow[col[n] + e] = acc[n][e];
+    }
+}
+
+static int split_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
 template <typename T>
 static int run_score_contract(const T* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
                               const double* sub_own, const double* add_other, double alpha, double* t, double* Z, double* csum,
@@ -167,15 +317,49 @@ static int run_score_contract(const T* X, int64_t I, int A, int B, const double*
   const int64_t stride = (int64_t)1024 * V;
   const int nv = (int)((P + stride - 1) / stride);
   constexpr int kMaxNV = (V == 4) ? 4 : 8;
-  if ((B % V) != 0 || nv > kMaxNV || P < stride / 2 || (reinterpret_cast<uintptr_t>(X) & 15) != 0) {
+  if ((B % V) != 0 || P < stride / 2 || P >= ((int64_t)1 << 31) || (reinterpret_cast<uintptr_t>(X) & 15) != 0) {
     set_error("score_contract: shape outside the row-in-registers form; use score + mode0_contract");
     return CMTFPLS_EUNSUPPORTED;
+  }
+  const bool kc = (stride % B) == 0;
+  if (nv > kMaxNV) {                                          // the row split over G workgroups
+    // vectors per lane and slab: 4 (16384 f32 / 8192 f64 elements per workgroup); 2 for f32 rows whose lanes meet different mode-2
+    // indices in their vectors (4 sets of wB would spill: 0.62 ms against 0.54 ms of two passes at 8192 x 250 x 200)
+    const int NVS = (sizeof(T) == 4 && !kc) ? 2 : 4;
+    const int G = (nv + NVS - 1) / NVS;
+    const int cus = split_cus() < kScGrid ? split_cus() : kScGrid;
+    const int S = (int)(I < cus / G ? I : cus / G);           // row streams: every one has a row (the kernel's clamped loads rely on it)
+    if (G > kSplitMaxG || S < 1) {
+      set_error("score_contract: row beyond 16 workgroups' registers; use score + mode0_contract");
+      return CMTFPLS_EUNSUPPORTED;
+    }
+    const size_t need = ((size_t)S * (P + 1) + (size_t)I * G) * sizeof(double);
+    if (!ws || ws_bytes < need) { set_error("score_contract: workspace too small"); return CMTFPLS_EWORKSPACE; }
+    double* part = static_cast<double*>(ws);
+    double* csum_part = part + (size_t)S * P;
+    unsigned long long* xch = reinterpret_cast<unsigned long long*>(csum_part + S);
+    if (hipMemsetAsync(xch, 0xFF, (size_t)I * G * sizeof(double), st) != hipSuccess) return check_launch("score_contract (exchange slots)");
+#define SPL(NVV, KCC, LG)                                                                                                          \
+  hipLaunchKernelGGL((score_contract_split_kernel<T, NVV, KCC, LG>), dim3(S * G), dim3(1024), 0, st, X, I, (unsigned)P, B, G, wA, wB, \
+                     shift, sub_own, add_other, alpha, t, part, csum ? csum_part : nullptr, xch)
+    // rows between publishing a partial sum and using the total: as many as the registers hold without spilling (measured at
+    // 256 x 256, profiles/r04m_split_rows.txt: f32 1 row 1.37 ms / 2 rows (spills) 1.73 ms at 32768 rows; f64 1.39 / 1.33 ms at 16384)
+    if constexpr (sizeof(T) == 8) {
+      if (kc) SPL(4, true, 2);
+      else SPL(4, false, 1);
+    } else {
+      if (kc) SPL(4, true, 1);
+      else SPL(2, false, 2);
+    }
+#undef SPL
+    launch_reduce_rows(part, S, P, Z, st);
+    if (csum) launch_reduce_rows(csum_part, S, 1, csum, st);
+    return check_launch("score_contract (split rows)");
   }
   const int grid = (int)(I < kScGrid ? I : kScGrid);
   if (!ws || ws_bytes < (size_t)grid * (P + 1) * sizeof(double)) { set_error("score_contract: workspace too small"); return CMTFPLS_EWORKSPACE; }
   double* part = static_cast<double*>(ws);
   double* csum_part = csum ? part + (size_t)grid * P : nullptr;
-  const bool kc = (stride % B) == 0;
 #define SCL(NVV)                                                                                                                  \
   do {                                                                                                                            \
     if (kc) hipLaunchKernelGGL((score_contract_rows_kernel<T, NVV, true>), dim3(grid), dim3(1024), 0, st, X, I, (unsigned)P, B, wA, wB, shift, sub_own, add_other, alpha, t, part, csum_part); \
@@ -202,7 +386,7 @@ using namespace cmtfpls;
 extern "C" {
 size_t cmtfpls_score_contract_workspace_bytes(int64_t I, int64_t P) {
   if (I <= 0 || P <= 0) return 0;
-  return (size_t)(I < kScGrid ? I : kScGrid) * (size_t)(P + 1) * sizeof(double);
+  return ((size_t)(I < kScGrid ? I : kScGrid) * (size_t)(P + 1) + (size_t)I * kSplitMaxG) * sizeof(double);   // partial rows of Z | csum | exchange slots
 }
 int cmtfpls_score_contract_f32(const float* X, int64_t I, int A, int B, const double* wA, const double* wB, const double* shift,
                                const double* sub_own, const double* add_other, double alpha, double* t, double* Z, double* csum,

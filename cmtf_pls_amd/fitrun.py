@@ -738,7 +738,8 @@ class FitRun(XcovMixin):
                 self.notes.append("uncentred xcov form declined: " + ("more than 64 components" if self.R > 64 else
                                                                       "f32 matrix precision or a backend without its kernels"))
             if nowrite and eng.opt.xcov_one_read and self.R > 1 and not one_read:
-                self.notes.append("one read per component declined: the row does not fit the registers of one workgroup "
-                                  "(rows of 2048..16384 f32 / 1024..8192 f64 elements)")
+                self.notes.append("one read per component declined: the row does not fit the registers of 1..16 workgroups "
+                                  "(rows of 2048..131072 f32 -- 262144 when the last mode divides 4096 -- / 1024..131072 f64 elements, "
+                                  "last mode a multiple of 4 / 2)")
         rep["declined"] = list(self.notes)
         return rep

@@ -204,8 +204,10 @@ int cmtfpls_axpy_scalar_f64(double* y, int64_t n, const double* a, const double*
  * r_j = X_0^T t_j kept from the pass that formed t_j.  sub_own = T[:, :a] (w_j^T w_a)_j makes t the score of the implicitly
  * deflated X_a; for coupled blocks (cmtf.py:120) add_other = the sum of the other blocks' scores and alpha = 1 / blocks make c the
  * block-averaged score the deflation uses, for the block that is read last.
- * A row lives in the registers of one 1024-thread workgroup: B % (16 / sizeof) == 0, 512 * (16 / sizeof) <= A * B <= 16384, no
- * missing values; CMTFPLS_EUNSUPPORTED otherwise (use cmtfpls_score_* + cmtfpls_mode0_contract_*).
+ * A row lives in the registers of one 1024-thread workgroup (A * B <= 16384) or, beyond that (round 4: the 256 x 256 rows of
+ * BASELINE configs[4]), of up to 16 co-resident workgroups that each hold a column slab and exchange the row's partial dot products
+ * through 8-byte agent-scope stores (value = flag, no fence): B % (16 / sizeof) == 0, 512 * (16 / sizeof) <= A * B <= 16 * 16384 (f32 with
+ * 4096 % B == 0) / 16 * 8192 (f64, other f32 rows), no missing values; CMTFPLS_EUNSUPPORTED otherwise (use cmtfpls_score_* + cmtfpls_mode0_contract_*).
  * csum (nullable): csum[0] = sum_i c[i] (the uncentred form's correction X_c^T c = X^T c - (1^T c) mean).
  * ws: cmtfpls_score_contract_workspace_bytes(I, A * B). */
 size_t cmtfpls_score_contract_workspace_bytes(int64_t I, int64_t P);

@@ -422,6 +422,13 @@ def test_xcov_fit_of_a_device_tensor_neither_writes_nor_copies_it(api):
     (256, 1, 4096, True),       # a matrix block
     (257, 3, 5000, False),      # 15000 elements: the last vector of most lanes does not exist
     (64, 16, 128, True),        # the shortest row the form takes for f32 (half the lanes idle)
+    # round 4: rows beyond one workgroup's registers, split over G co-resident workgroups that exchange the partial dot products
+    (700, 256, 256, True),      # the north-star row: 4 slabs (f32) / 8 (f64), 64 / 32 row streams, more rows than streams
+    (40, 256, 256, False),      # fewer rows than row streams: some streams have nothing to do
+    (301, 200, 128, True),      # 25600 elements: the last slab is partly empty
+    (150, 3, 40000, False),     # a lane's vectors meet different mode-2 indices: 15 slabs of 8192 elements for f32 and f64
+    (33, 3, 50000, False),      # 150000 elements: declined by f64 and by this f32 form (beyond 16 slabs of 8192)
+    (129, 1, 100000, True),     # a matrix block with a 100000-long row
 ])
 def test_score_contract_kernel_equals_the_two_passes(be, dtype, I, A, B, shift):
     rng = np.random.default_rng(I + A + B)
@@ -433,6 +440,10 @@ def test_score_contract_kernel_equals_the_two_passes(be, dtype, I, A, B, shift):
     X = _dev(x).to(dtype)
     t, Z = be.empty(I), be.empty(A * B)
     out = be.score_contract(X, A, B, _dev(wA), _dev(wB), _dev(sh) if shift else None, t, Z)
+    V = 4 if dtype == torch.float32 else 2
+    if A * B > 16 * (16384 if (dtype == torch.float32 and (1024 * V) % B == 0) else 8192):
+        assert out is None
+        return
     assert out is not None
     want_t = x @ np.kron(wA, wB) - (1.25 if shift else 0.0)
     want_Z = x.T @ want_t
@@ -457,16 +468,22 @@ def test_score_contract_kernel_equals_the_two_passes(be, dtype, I, A, B, shift):
     assert np.abs(Z.cpu().numpy() - x.T @ want_c).max() <= 1e-12 * np.abs(x.T @ want_c).max()
 
 
-def test_score_contract_declines_rows_outside_the_registers_of_one_workgroup(be):
-    w = be.zeros(200)
-    for dtype, A, B in ((torch.float32, 200, 128), (torch.float64, 200, 128), (torch.float32, 4, 200), (torch.float32, 64, 66)):
+def test_score_contract_declines_rows_outside_the_registers_of_its_workgroups(be):
+    """Rows shorter than half a workgroup's stride, a last mode that is not a whole number of 16-byte vectors, rows beyond 16
+    workgroups' registers (round 4 lifted the limit from ONE workgroup's: 200 x 128 is served now)."""
+    w = be.zeros(2100)
+    for dtype, A, B in ((torch.float32, 2100, 128), (torch.float64, 1100, 128), (torch.float32, 4, 200), (torch.float32, 64, 66)):
         X = torch.zeros(8, A * B, dtype=dtype, device="cuda:0")
         assert be.score_contract(X, A, B, w[:A], w[:B], None, be.empty(8), be.empty(A * B)) is None
+    for dtype in (torch.float32, torch.float64):
+        X = torch.zeros(8, 200 * 128, dtype=dtype, device="cuda:0")
+        assert be.score_contract(X, 200, 128, w[:200], w[:128], None, be.empty(8), be.empty(200 * 128)) is not None
 
 
 @pytest.mark.parametrize("raw", [True, False])
 @pytest.mark.parametrize("dtype,shape", [("float32", (160, 128, 128)), ("float64", (160, 64, 128)), ("float32", (500, 4096)),
-                                         ("float32", (300, 8, 16, 32))])
+                                         ("float32", (300, 8, 16, 32)),
+                                         ("float32", (150, 256, 256)), ("float64", (90, 160, 128))])     # round 4: rows split over workgroups
 def test_xcov_fit_with_one_read_per_component_equals_the_two_reads(api, monkeypatch, dtype, shape, raw):
     """tPLS(algorithm="xcov") on one block reads X once per component (plus the two reads that build S and the norm): the second
     read is replaced by X_0^T yhat = sum_j b_j r_j with r_j = X_0^T t_j kept from the pass that formed t_j.  Same iterations, same

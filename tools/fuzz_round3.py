@@ -146,7 +146,8 @@ for case in range(N):
                             sub_own=None if sub is None else dev(sub), add_other=None if oth is None else dev(oth), alpha=alpha)
     P = A * B
     if out is None:
-        assert P > 16384 or P < 512 * V, ("score_contract declined", I, A, B, dt)
+        lim = 16 * (16384 if (V == 4 and (1024 * V) % B == 0) else 8192)                       # (round 4: up to 16 workgroups share a row)
+        assert P > lim or P < 512 * V, ("score_contract declined", I, A, B, dt)
         continue
     n_sc += 1
     want_t = x @ np.kron(wA, wB) - (0.0 if sh is None else sh[0]) - (0.0 if sub is None else sub)
