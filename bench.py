@@ -275,7 +275,30 @@ def north_star_leg(be, eng_cls, device, steps, repeats, timer):
            "end_to_end_GBps": 2 * xbytes / (med / steps) / 1e9, "sweeps": sweeps, "deflation": defl,
            "deflation_frac_of_hbm_peak": defl["deflate"]["frac"], "finish_component_ms": finish_ms, "preprocess_s": pre_s,
            "target": ">= 50 it/s, >= 40 % of the HBM roofline on the deflation (BASELINE.json north_star)"}
-    del run, X, Y
+    # sec-to-fit at this shape through the cross-covariance form, on the caller's UNCENTRED tensor (never written, never
+    # copied): the same synthetic tensor formed again (the legs above centred and deflated it in place).  Default tol / max_iter.
+    del run, X, Y, tz, Zs
+    torch.cuda.empty_cache()
+    X, Y = synthetic_shard_device((I, J, K), M, R, error=0.1, seed=215, device=device)
+    secs = []
+    for _ in range(2):
+        Yf = Y.clone()                                  # the engine centres and deflates the responses it is handed in place
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sx = eng.fit([X], Yf, R, tol=1e-8, max_iter=100, coupled=False, algorithm="xcov")
+        torch.cuda.synchronize()
+        secs.append(time.perf_counter() - t0)
+        rep = sx.report
+        if rep.get("x_written") or not rep.get("raw"):  # X was centred / deflated in place: a second fit would see other data
+            secs.append(secs[0])
+            break
+    out["fit_xcov"] = {"seconds": secs[1], "first_call_seconds": secs[0], "n_iter": list(sx.n_iter),
+                       "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
+                       "x_reads_in_all": (R + 2) if rep.get("one_read") else 2 * R + 1,
+                       "floor_s_at_the_read_ceiling": ((R + 2) if rep.get("one_read") else 2 * R + 1) * xbytes / 6.95e12,
+                       "path": {k: rep.get(k) for k in ("algorithm", "raw", "x_copy", "x_written", "one_read", "x_passes_per_component",
+                                                        "pipelined", "declined")}}
+    del X, Y, Yf, sx
     torch.cuda.empty_cache()
     return out
 

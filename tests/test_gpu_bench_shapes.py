@@ -80,6 +80,8 @@ def test_cfg5_full_size_properties(api):
     xc = api.tPLS(2, dtype="float32", algorithm="xcov")
     xc.fit(X, Y, max_iter=12)
     assert m.n_iter_ == xc.n_iter_
+    # round 4: the 256 x 256 row is served by the one-read form (the row split over four workgroups), on the uncentred tensor
+    assert xc.fit_report_["one_read"] and xc.fit_report_["raw"] and not xc.fit_report_["x_written"], xc.fit_report_
     col_close(xc.X_factors[0], m.X_factors[0])
     assert_allclose(xc.R2X, m.R2X, rtol=1e-6)
     assert_allclose(xc.R2Y, m.R2Y, rtol=1e-6)
