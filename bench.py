@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--repeats", type=int, default=5, help="timed windows of exactly --steps iterations each; value = median")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 262144x256x256 leg (BASELINE.json north_star)")
     ap.add_argument("--north-star-steps", type=int, default=10)
+    ap.add_argument("--rank1-chain", type=int, default=1,
+                    help="0: the launch-per-squaring form of the rank-1 extraction instead of the one-launch chain (A/B)")
     ap.add_argument("--capture-collectives", type=int, default=0,
                     help="N > 1: capture the two per-iteration all-reduces inside the iteration's HIP graph (EngineOptions.capture_collectives; "
                          "falls back to the segment-wise form when the capture fails)")
@@ -337,6 +339,9 @@ def main():
         raise SystemExit(proc.returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_DUMP_AFTER"):                  # rehearsals: every thread's stack after N seconds, then exit (a hung rank says where)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_DUMP_AFTER"]), exit=True)
     # rehearsal hooks (one-GPU box): BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo
     # replaces RCCL, which refuses two ranks on one device; BENCH_FORCE_DIST=1 makes a single rank create
     # its RCCL communicator and issue the engine's collectives anyway; the driver's runs use none of them
@@ -384,6 +389,9 @@ def main():
     assert I_total % world == 0
     rows = I_total // world
     X, Y = synth_shard(I_total, J, K, M, R, args.noise, rank * rows, rows, device)
+    if not args.rank1_chain:
+        from cmtf_pls_amd import _lib
+        _lib.load().cmtfpls_rank1_chain_enable(0)
     be = HipBackend(device)
     # the product iteration calls the fused forms (u = Y q inside the contraction, Y^T t inside the score);
     # the unfused names stay bracketed for shapes that fall back to them

@@ -42,6 +42,9 @@ SIGNATURES = {
     "cmtfpls_rank1_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cmtfpls_rank1_score_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, c_size_t, _P]),
     "cmtfpls_rank1_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_rank1_launches_f64": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "cmtfpls_rank1_chain_enable": (None, [c_int]),
+    "cmtfpls_rank1_chain_enabled": (c_int, []),
     "cmtfpls_normalize_f64": (c_int, [_P, c_int64, _P, _P]),
     "cmtfpls_rank1_tensor_workspace_bytes": (c_size_t, [_P, c_int]),
     "cmtfpls_rank1_tensor_f64": (c_int, [_P, _P, c_int, c_double, _P, c_int, _P, c_int, _P, c_size_t, _P]),

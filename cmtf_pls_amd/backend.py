@@ -31,6 +31,8 @@ class HipBackend:
         self._ws = {}
         self._status_slots = {}        # (slot, words) -> pinned host buffer + event of status_snapshot
         self.rank1_squarings = 30      # budget ceiling: resolves sigma_2/sigma_1 up to 1 - 1e-8
+        # min(A, B) up to which cmtfpls_rank1_* runs all squarings in one launch (csrc/rank1.hip); 0 once the process switched it off
+        self.rank1_chain_side = 256 if self.lib.cmtfpls_rank1_chain_enabled() else 0
 
     # -- helpers ---------------------------------------------------------------------------
     def _stream(self):
@@ -126,12 +128,19 @@ class HipBackend:
 
     # -- K2: tpls.py:84-90 -------------------------------------------------------------------
     def rank1(self, Z: torch.Tensor, A: int, B: int, wA: torch.Tensor, wB: torch.Tensor,
-              info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None) -> None:
-        """info (2 doubles, optional): [converged within the budget, squarings computed]."""
+              info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None, launches: bool = False) -> None:
+        """info (2 doubles, optional): [converged within the budget, squarings computed].  launches: the launch-per-squaring
+        form (cmtfpls_rank1_launches_f64) instead of the one-launch chain the entry takes for min(A, B) <= 256 -- same bits."""
         ws = self._workspace("rank1", self.lib.cmtfpls_rank1_workspace_bytes(A, B))
-        _lib.check(self.lib.cmtfpls_rank1_f64(_ptr(Z), A, B, _ptr(wA), _ptr(wB), None, _ptr(info),
-                                              int(n_squarings or self.rank1_squarings),
-                                              _ptr(ws), ws.numel(), self._stream()), "rank1")
+        fn = self.lib.cmtfpls_rank1_launches_f64 if launches else self.lib.cmtfpls_rank1_f64
+        _lib.check(fn(_ptr(Z), A, B, _ptr(wA), _ptr(wB), None, _ptr(info), int(n_squarings or self.rank1_squarings),
+                      _ptr(ws), ws.numel(), self._stream()), "rank1")
+
+    def rank1_chain_gave_up(self) -> None:
+        """An extraction reported info = [0, -1]: a workgroup of the one-launch chain of squarings never became resident (the GPU
+        is shared with another process).  From here on every entry of this process takes the launch-per-squaring form."""
+        self.lib.cmtfpls_rank1_chain_enable(0)
+        self.rank1_chain_side = 0
 
     def rank1_tensor(self, Z: torch.Tensor, dims, tol: float, factors: torch.Tensor,
                      info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None) -> None:

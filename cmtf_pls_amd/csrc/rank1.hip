@@ -11,6 +11,7 @@
 // Z itself (M = Z or Z^T), which also gives exact zeros in the loadings wherever Z has an all-zero
 // row or column (tests/test_tpls.py:98-104 relies on that).
 #include "common.hpp"
+#include <atomic>
 
 namespace cmtfpls {
 
@@ -203,6 +204,208 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
   }
 }
 
+// ---- the whole chain of squarings in ONE launch (round 4) -------------------------------------------------------------------
+// A launch per squaring costs a dispatch (2.5 us back to back) plus its own ramp: 6.4 us per step inside a fit for 0.5 us of
+// matrix work (profiles/r04o_*).  Here the (n/16)^2 workgroups of the step kernel stay resident (n <= 256: at most 256 workgroups
+// of 256 threads) and walk steps 0 .. n_squarings themselves.  What a step needs from the other workgroups -- two 16-row panels
+// of G_{s-1}, the diagonal tiles' traces, every tile's sum of squares -- is passed WITHOUT a grid barrier and without release
+// fences: each G_s has its own buffer, preset to an all-ones pattern no product yields (one memset per extraction), every element
+// is written with an 8-byte agent-scope store and IS its own flag; a consumer simply loads its MFMA operands with agent-scope
+// loads (which by-pass the XCD's L2: measured one-way 0.4 us, tools/exp/xch_latency.hip) and repeats the batch while a lane still
+// sees the preset.  Same tile arithmetic, same summation orders, same control decisions as syrk_step_kernel -- every workgroup
+// derives them from the same bits -- so the chain is bit-identical to the launch-per-step form.  Spins are bounded: a wavefront
+// that gives up continues on NaNs (which it publishes: nobody else waits), and the extraction reports "not converged".
+constexpr unsigned long long kChainEmpty = ~0ull;
+constexpr int kChainMaxSteps = 31;            // squarings of one chain launch (the engine's budget ceiling is 30)
+constexpr int kChainSpin = 1 << 15;           // tries before a wavefront gives up (tens of milliseconds; a healthy wait is a few microseconds)
+
+__device__ __forceinline__ double chain_ld(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void chain_st(double* p, double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  if (b == kChainEmpty) b = 0x7FF8000000000000ull;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool chain_empty(double v) { return (unsigned long long)__double_as_longlong(v) == kChainEmpty; }
+
+// the preset as an ordinary kernel (a kernel node under graph capture like every other launch of the sequence)
+__global__ __launch_bounds__(256) void chain_preset_kernel(unsigned long long* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = kChainEmpty;
+}
+
+// gbufs: (n_squarings + 1) matrices of n x n (G_s at s * n * n); trs: (n_squarings + 1) x nt; fros: (n_squarings + 1) x nt * nt --
+// one contiguous region preset to 0xFF bytes by the caller.
+__global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const double* __restrict__ M0, int n, int k0,
+                                                                 double* gbufs, double* trs, double* fros, double* gave_up,
+                                                                 Rank1Ctl* __restrict__ ctl, int n_squarings) {
+  constexpr int KC = 128, KW = 8, LDP = KC + 2;            // chunk width; columns per lane per chunk; padded panel row in LDS
+  __shared__ double pan[2][kTile][LDP];                    // the two 16-row panels of the current chunk (steps >= 1)
+  __shared__ double red[2][4][kTile * kTile];              // (by step parity: no barrier between a step's last read and the next step's writes)
+  __shared__ double diag[2][kTile];
+  __shared__ double fsum[2][4];
+  __shared__ double s_scale[2];
+  __shared__ int s_dec[2];
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTile + tx;
+  const int lane = tid & 63, wv = tid >> 6, ri = lane & 15, kq = lane >> 4;
+  const int nt = (n + kTile - 1) / kTile, nt2 = nt * nt;
+  const int i0 = blockIdx.y * kTile, j0 = blockIdx.x * kTile;
+  const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0;
+  const bool ra = (i0 + ri) < n, rb = (j0 + ri) < n;
+  const int cl = 32 * wv + KW * kq;
+  const int64_t nn = (int64_t)n * n;
+  const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+  bool dead = false;                                       // this wavefront gave up on a partner
+  if (first_wg && tid == 0) { ctl->done = 0; ctl->final_buf = -1; ctl->steps_used = 0; ctl->last_step = -1; }
+  // ---- step 0: G_0 = M0 M0^T, operands straight from global memory (Z was written before this launch) ----
+  // ---- step s >= 1: the panels of G_{s-1} are fetched by the WHOLE workgroup in coalesced 8-byte agent-scope loads (element
+  // e = tid + 256 i of a 16 x 128 chunk: 512 contiguous bytes per instruction -- as MFMA operands straight from memory every
+  // load instruction would touch 64 lines, and un-cached loads are paid per line), each wavefront repeating its own sixteen
+  // while one still shows the preset; then staged through LDS into the MFMA layout.  Wavefront 0 fetches the control words in
+  // the same batch and decides for the workgroup.
+  int last_step = -1;                                      // (what syrk_step_kernel keeps in ctl->last_step)
+  for (int step = 0; step <= n_squarings; ++step) {
+    if (last_step >= 0) break;                             // the previous step declared its own output final
+    const int par = step & 1;
+    const double* __restrict__ M = step == 0 ? M0 : gbufs + (int64_t)(step - 1) * nn;
+    const int k = step == 0 ? k0 : n, ld = k;
+    double* C = gbufs + (int64_t)step * nn;
+    double a[KW], b[KW];
+    double scale = 1.0;
+    d4r_t acc = d4r_t{0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < k; kk += KC) {
+      if (step == 0) {
+        const double* __restrict__ rowa = M + (int64_t)(ra ? i0 + ri : 0) * ld;
+        const double* __restrict__ rowb = M + (int64_t)(rb ? j0 + ri : 0) * ld;
+#pragma unroll
+        for (int s2 = 0; s2 < KW; ++s2) {
+          const int c = kk + cl + s2;
+          const int cc = (c < k) ? c : 0;
+          a[s2] = rowa[cc];
+          b[s2] = rowb[cc];
+        }
+      } else {
+        double va[8], vb[8], trv = 0.0, f[4] = {0.0, 0.0, 0.0, 0.0};
+        const bool ctl_wave = (wv == 0 && kk == 0);
+        const double* tp = trs + (int64_t)(step - 1) * nt;
+        const double* fp = fros + (int64_t)(step - 1) * nt2;
+        unsigned offa[8], offb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int e = tid + 256 * i, r = e >> 7, c = kk + (e & 127);
+          const int cc = (c < k) ? c : 0;
+          const int rra = (i0 + r < n) ? i0 + r : 0, rrb = (j0 + r < n) ? j0 + r : 0;
+          offa[i] = (unsigned)(rra * ld + cc);
+          offb[i] = (unsigned)(rrb * ld + cc);
+        }
+        int spins = 0;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {                     // (uniform base + 32-bit lane offset: n <= 256)
+            va[i] = chain_ld(M + offa[i]);
+            vb[i] = chain_ld(M + offb[i]);
+          }
+          if (ctl_wave) {
+            trv = chain_ld(tp + ((lane < nt) ? lane : 0));
+#pragma unroll
+            for (int w = 0; w < 4; ++w) f[w] = chain_ld(fp + ((64 * w + lane < nt2) ? 64 * w + lane : 0));
+            ok = !chain_empty(trv);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) ok = ok && !chain_empty(f[w]);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ok = ok && !chain_empty(va[i]) && !chain_empty(vb[i]);
+          if (dead || __all(ok)) break;
+          if (++spins > kChainSpin) {                      // a partner is not resident (the GPU is shared): say so, go on with NaNs
+            dead = true;
+            if (lane == 0) chain_st(gave_up, 1.0);
+            break;
+          }
+        }
+        if (kk > 0) __syncthreads();                       // the previous chunk's panels have been consumed
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int e = tid + 256 * i, r = e >> 7, c = e & 127;
+          pan[0][r][c] = dead ? qnan : va[i];
+          pan[1][r][c] = dead ? qnan : vb[i];
+        }
+        if (ctl_wave) {
+          // scale and exit decisions in syrk_step_kernel's orders: fro = ((w0 + w1) + w2) + w3 with w_i the butterfly sum of entries
+          // 64 i .. 64 i + 63, the trace added in tile order.  (A control wavefront that gave up decides "go on": the chain then
+          // walks to its last step on NaNs.)
+          double fw[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) fw[w] = wave_sum((64 * w + lane < nt2) ? f[w] : 0.0);
+          const double fro_in = ((fw[0] + fw[1]) + fw[2]) + fw[3];
+          double tr1 = 0.0;
+          for (int i = 0; i < nt; ++i) tr1 += __shfl(trv, i, kWave);
+          double sc = 1.0;
+          if ((tr1 > 0.0) && isfinite(tr1)) {
+            int e;
+            frexp(tr1, &e);
+            sc = ldexp(1.0, -e);
+          }
+          const double rho = fro_in / (tr1 * tr1);
+          const bool rank_one_in = !dead && (!(tr1 > 0.0) || rho >= 1.0 - 1e-13);     // the input already is the result
+          const bool rank_one_out = !dead && rho >= 1.0 - 1e-7;                        // this step's output will be
+          if (lane == 0) {
+            s_scale[par] = sc;
+            s_dec[par] = rank_one_in ? 1 : (rank_one_out ? 2 : 0);
+            if (first_wg) {
+              if (rank_one_in) { ctl->done = 1; ctl->final_buf = step - 1; }
+              else {
+                ctl->steps_used = step;
+                if (rank_one_out) { ctl->last_step = step; ctl->final_buf = step; }
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (kk == 0) {
+          const int dec = s_dec[par];
+          if (dec == 1) break;
+          if (dec == 2) last_step = step;
+          scale = s_scale[par];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < KW; ++s2) {
+          a[s2] = pan[0][ri][cl + s2];
+          b[s2] = pan[1][ri][cl + s2];
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < KW; ++s2) {
+        const bool cok = (kk + cl + s2) < k;
+        const double av = (ra && cok) ? a[s2] : 0.0;
+        const double bv = (rb && cok) ? b[s2] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+    }
+    if (step >= 1 && s_dec[par] == 1) break;               // (left the chunk loop through the decision: the input is the result)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[par][wv][(kq + 4 * e) * kTile + ri] = acc[e];
+    __syncthreads();
+    double cacc = ((red[par][0][tid] + red[par][1][tid]) + red[par][2][tid]) + red[par][3][tid];
+    cacc *= scale * scale;
+    const bool inside = (i0 + ty < n && j0 + tx < n);
+    if (inside) chain_st(C + (int64_t)(i0 + ty) * n + (j0 + tx), cacc);
+    double sq = inside ? cacc * cacc : 0.0;
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) fsum[par][tid >> 6] = sq;
+    if (blockIdx.x == blockIdx.y && tx == ty) diag[par][tx] = (i0 + ty < n) ? cacc : 0.0;
+    __syncthreads();
+    if (tid == 0) {
+      chain_st(fros + (int64_t)step * nt2 + blockIdx.y * nt + blockIdx.x, ((fsum[par][0] + fsum[par][1]) + fsum[par][2]) + fsum[par][3]);
+      if (blockIdx.x == blockIdx.y) {
+        double t = 0.0;
+        for (int l = 0; l < kTile; ++l) t += diag[par][l];
+        chain_st(trs + (int64_t)step * nt + blockIdx.x, t);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ Z, int A, int B, double* __restrict__ Zt) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)A * B) return;
@@ -217,7 +420,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
 //     one launch instead of two (round 2).  A zero row of M is a zero row of G_0: its entry of x is exactly 0, as
 //     a zero column of M gives an exact 0 in y (tests/test_tpls.py:98-104 relies on both).
 __global__ __launch_bounds__(256) void rank1_seed_xy_kernel(const double* __restrict__ M, int n, int k,
-                                                           const double* __restrict__ buf0, const double* __restrict__ buf1,
+                                                           const double* __restrict__ gbase, int64_t gstride,
                                                            const double* __restrict__ G0,
                                                            const Rank1Ctl* __restrict__ ctl, int last_buf, int ny_blocks,
                                                            double* __restrict__ y, double* __restrict__ x) {
@@ -226,8 +429,8 @@ __global__ __launch_bounds__(256) void rank1_seed_xy_kernel(const double* __rest
   __shared__ double rsum[8][33];
   __shared__ double bestv[4];
   __shared__ int besti[4];
-  const int fb = (ctl->final_buf >= 0) ? ctl->final_buf : last_buf;
-  const double* G = fb ? buf1 : buf0;
+  const int fb = (ctl->final_buf >= 0) ? ctl->final_buf : last_buf;     // ping-pong buffer (launch per step) or step index (chain)
+  const double* G = gbase + (int64_t)fb * gstride;
   // argmax of the diagonal (first index on ties)
   double bv = -1.0;
   int bi = 0;
@@ -287,10 +490,20 @@ __global__ __launch_bounds__(256) void rank1_seed_xy_kernel(const double* __rest
 
 // F3: normalise x and y, apply the sign rule, write wA / wB / sigma / info   (1024 threads; x, y may
 // live in global memory or in LDS)
+// info for the caller: [converged within the budget, squarings computed]; [0, -1] when the one-launch chain gave up waiting for a
+// workgroup that never became resident (gave: its flag word, nullptr for the launch-per-squaring form): the loadings are NaN
+// and the caller must repeat the extraction through cmtfpls_rank1_launches_f64 / with the chain switched off
+__device__ __forceinline__ void rank1_write_info(double* __restrict__ info, const Rank1Ctl* __restrict__ ctl, const double* gave) {
+  if (!info) return;
+  if (gave && !chain_empty(chain_ld(gave))) { info[0] = 0.0; info[1] = -1.0; return; }
+  info[0] = (ctl->done || ctl->last_step >= 0) ? 1.0 : 0.0;
+  info[1] = (double)ctl->steps_used;
+}
+
 __device__ __forceinline__ void rank1_final_body(const double* x, const double* y,
                                                  int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
                                                  double* __restrict__ wA, double* __restrict__ wB,
-                                                 double* __restrict__ sigma, double* __restrict__ info) {
+                                                 double* __restrict__ sigma, double* __restrict__ info, const double* gave) {
   __shared__ double red[2][16];
   __shared__ double bestv[16];
   __shared__ int besti[16];
@@ -320,7 +533,10 @@ __device__ __forceinline__ void rank1_final_body(const double* x, const double* 
   bi = besti[0];
   for (int w = 1; w < 16; ++w)
     if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
-  const double sgn = (vb[bi] < 0.0) ? -1.0 : 1.0;
+  // a chain that gave up may still have reached a usable final G (the give-up fell into its last step): the caller is told to
+  // repeat the extraction either way, and every rank of a sharded fit must see that in the data -- the loadings are NaN then
+  const bool gv = gave && !chain_empty(chain_ld(gave));
+  const double sgn = gv ? __longlong_as_double(0x7FF8000000000000ll) : ((vb[bi] < 0.0) ? -1.0 : 1.0);
   double* ox = x_is_A ? wA : wB;
   double* oy = x_is_A ? wB : wA;
   for (int i = threadIdx.x; i < n; i += 1024) ox[i] = sgn * (x[i] / nx);
@@ -328,15 +544,15 @@ __device__ __forceinline__ void rank1_final_body(const double* x, const double* 
   if (threadIdx.x == 0) {
     // y = M^T seed has norm ~ sigma, x = M y has norm ~ sigma^2: sigma_1 = |x| / |y|
     if (sigma) sigma[0] = nx / ny;
-    if (info) { info[0] = (ctl->done || ctl->last_step >= 0) ? 1.0 : 0.0; info[1] = (double)ctl->steps_used; }
+    rank1_write_info(info, ctl, gave);
   }
 }
 
 __global__ __launch_bounds__(1024) void rank1_final_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                                           int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
                                                           double* __restrict__ wA, double* __restrict__ wB,
-                                                          double* __restrict__ sigma, double* __restrict__ info) {
-  rank1_final_body(x, y, n, k, x_is_A, ctl, wA, wB, sigma, info);
+                                                          double* __restrict__ sigma, double* __restrict__ info, const double* gave) {
+  rank1_final_body(x, y, n, k, x_is_A, ctl, wA, wB, sigma, info, gave);
 }
 
 // The last kernel of the extraction AND the score of a FEW LONG rows with the loading it has just formed (round 3): inside the
@@ -349,7 +565,7 @@ __global__ __launch_bounds__(1024) void rank1_final_score_kernel(const double* _
                                                                 int n, int k, int x_is_A, const Rank1Ctl* __restrict__ ctl,
                                                                 double* __restrict__ wA, double* __restrict__ wB,
                                                                 double* __restrict__ info, const double* __restrict__ S, int A, int B,
-                                                                double* __restrict__ t) {
+                                                                double* __restrict__ t, const double* gave) {
   extern __shared__ double lds[];
   __shared__ double red[2][16];
   __shared__ double bestv[16];
@@ -381,7 +597,8 @@ __global__ __launch_bounds__(1024) void rank1_final_score_kernel(const double* _
   bi = besti[0];
   for (int w = 1; w < 16; ++w)
     if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
-  const double sgn = (vb[bi] < 0.0) ? -1.0 : 1.0;
+  const bool gv = gave && !chain_empty(chain_ld(gave));    // (as rank1_final_body: NaN loadings when the chain gave up)
+  const double sgn = gv ? __longlong_as_double(0x7FF8000000000000ll) : ((vb[bi] < 0.0) ? -1.0 : 1.0);
   double* lx = x_is_A ? sA : sB;
   double* ly = x_is_A ? sB : sA;
   double* ox = x_is_A ? wA : wB;
@@ -397,7 +614,7 @@ __global__ __launch_bounds__(1024) void rank1_final_score_kernel(const double* _
     ly[i] = v;
     if (store) oy[i] = v;
   }
-  if (store && threadIdx.x == 0 && info) { info[0] = (ctl->done || ctl->last_step >= 0) ? 1.0 : 0.0; info[1] = (double)ctl->steps_used; }
+  if (store && threadIdx.x == 0) rank1_write_info(info, ctl, gave);
   __syncthreads();
   // the row, as score_fewrows_kernel<double, false>
   using VT = Pack<double, 2>;
@@ -435,6 +652,11 @@ __global__ __launch_bounds__(1024) void rank1_final_score_kernel(const double* _
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// The one-launch chain needs every one of its workgroups resident at once.  On a GPU this process has to itself (one process
+// per GPU: the deployment) that holds; where it does not (several processes on one card) an extraction reports info = [0, -1] and the
+// caller switches the chain off for the rest of the process: cmtfpls_rank1_chain_enable(0).
+static std::atomic<int> g_chain_on{1};
+
 }  // namespace cmtfpls
 
 using namespace cmtfpls;
@@ -444,16 +666,26 @@ extern "C" {
 size_t cmtfpls_rank1_workspace_bytes(int A, int B) {
   if (A <= 0 || B <= 0) return 0;
   const size_t n = (size_t)(A < B ? A : B), k = (size_t)(A < B ? B : A);
-  return align_up(rank1_ctl_bytes((int)((n + kTile - 1) / kTile)), 256) + 3 * align_up(n * n * sizeof(double), 256) +
-         align_up((size_t)A * B * sizeof(double), 256) + align_up(n * sizeof(double), 256) + align_up(k * sizeof(double), 256);
+  const size_t nt = (n + kTile - 1) / kTile;
+  const size_t chain = nt * nt <= 256 ? align_up(((size_t)(kChainMaxSteps + 1) * (n * n + nt + nt * nt) + 1) * sizeof(double), 256) : 0;
+  return align_up(rank1_ctl_bytes((int)nt), 256) + 3 * align_up(n * n * sizeof(double), 256) +
+         align_up((size_t)A * B * sizeof(double), 256) + align_up(n * sizeof(double), 256) + align_up(k * sizeof(double), 256) + chain;
 }
 
 static int rank1_run(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
-                     int n_squarings, void* ws, size_t ws_bytes, void* stream, const double* S, int M, double* tq);
+                     int n_squarings, void* ws, size_t ws_bytes, void* stream, const double* S, int M, double* tq, bool allow_chain = true);
 
 int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
                       int n_squarings, void* ws, size_t ws_bytes, void* stream) {
   return rank1_run(Z, A, B, wA, wB, sigma, info, n_squarings, ws, ws_bytes, stream, nullptr, 0, nullptr);
+}
+
+void cmtfpls_rank1_chain_enable(int on) { g_chain_on.store((on == 1 || on == 2) ? on : 0, std::memory_order_relaxed); }
+int cmtfpls_rank1_chain_enabled(void) { return g_chain_on.load(std::memory_order_relaxed); }
+
+int cmtfpls_rank1_launches_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
+                               int n_squarings, void* ws, size_t ws_bytes, void* stream) {
+  return rank1_run(Z, A, B, wA, wB, sigma, info, n_squarings, ws, ws_bytes, stream, nullptr, 0, nullptr, false);
 }
 
 int cmtfpls_rank1_score_f64(const double* Z, int A, int B, double* wA, double* wB, double* info, int n_squarings,
@@ -470,7 +702,7 @@ int cmtfpls_rank1_score_f64(const double* Z, int A, int B, double* wA, double* w
 }
 
 static int rank1_run(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
-                     int n_squarings, void* ws, size_t ws_bytes, void* stream, const double* S, int M, double* tq) {
+                     int n_squarings, void* ws, size_t ws_bytes, void* stream, const double* S, int M, double* tq, bool allow_chain) {
   if (!Z || !wA || !wB || A <= 0 || B <= 0) { set_error("rank1: bad argument"); return CMTFPLS_EINVAL; }
   const int n = A < B ? A : B, k = A < B ? B : A;
   if (n > kTile * kMaxTiles) { set_error("rank1: min(A, B) > 4096 unsupported"); return CMTFPLS_EUNSUPPORTED; }
@@ -493,6 +725,8 @@ static int rank1_run(const double* Z, int A, int B, double* wA, double* wB, doub
   double* xv = reinterpret_cast<double*>(p);
   p += align_up((size_t)n * sizeof(double), 256);
   double* yv = reinterpret_cast<double*>(p);
+  p += align_up((size_t)k * sizeof(double), 256);
+  double* chain_region = reinterpret_cast<double*>(p);
 
   const double* M0 = Z;   // n x k with n on the smaller side
   if (A > B) {
@@ -502,24 +736,43 @@ static int rank1_run(const double* Z, int A, int B, double* wA, double* wB, doub
   }
   const int nt = (n + kTile - 1) / kTile;
   const dim3 grid(nt, nt), block(kTile, kTile);
-  // step 0: G_0 = M0 M0^T -> buf0 ; step s: G_s = scale^2 G_{s-1} G_{s-1}^T -> buf[s & 1]
-  hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, M0, n, k, k, buf0, ctl, 0, 0, g0keep);
-  for (int s = 1; s <= n_squarings; ++s) {
-    const double* in = (s & 1) ? buf0 : buf1;
-    double* out = (s & 1) ? buf1 : buf0;
-    hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, in, n, n, n, out, ctl, s, s & 1, (double*)nullptr);
-  }
-  // (a single-workgroup fusion of the finish kernels was measured in round 1: no faster than parallel launches)
   const int ny_blocks = (k + 31) / 32;
-  hipLaunchKernelGGL(rank1_seed_xy_kernel, dim3(ny_blocks + (n + 3) / 4), dim3(256), (size_t)n * sizeof(double), st,
-                     M0, n, k, buf0, buf1, g0keep, ctl, n_squarings & 1, ny_blocks, yv, xv);
+  const double* gave = nullptr;
+  if (allow_chain && g_chain_on.load(std::memory_order_relaxed) && nt * nt <= 256 && n_squarings <= kChainMaxSteps) {
+    // every step in ONE launch (syrk_chain_kernel): G_s | traces | sums of squares of steps 0 .. n_squarings, preset to the
+    // pattern that means "not yet written"
+    const size_t nn = (size_t)n * n, steps = (size_t)n_squarings + 1;
+    double* gbufs = chain_region;
+    double* trs = gbufs + steps * nn;
+    double* fros = trs + steps * nt;
+    double* gave_up = fros + steps * (size_t)nt * nt;       // stays at the preset unless a wavefront gives up
+    gave = gave_up;
+    const int64_t words = (int64_t)(steps * (nn + nt + (size_t)nt * nt) + 1);
+    hipLaunchKernelGGL(chain_preset_kernel, dim3((unsigned)((words + 2047) / 2048)), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(chain_region), words);
+    // (mode 2, tests only: the last row of workgroups is not launched, so its partners wait in vain and the give-up path runs)
+    const dim3 cgrid(nt, (g_chain_on.load(std::memory_order_relaxed) == 2 && nt > 1) ? nt - 1 : nt);
+    hipLaunchKernelGGL(syrk_chain_kernel, cgrid, block, 0, st, M0, n, k, gbufs, trs, fros, gave_up, ctl, n_squarings);
+    hipLaunchKernelGGL(rank1_seed_xy_kernel, dim3(ny_blocks + (n + 3) / 4), dim3(256), (size_t)n * sizeof(double), st,
+                       M0, n, k, gbufs, (int64_t)nn, gbufs, ctl, n_squarings, ny_blocks, yv, xv);
+  } else {
+    // step 0: G_0 = M0 M0^T -> buf0 ; step s: G_s = scale^2 G_{s-1} G_{s-1}^T -> buf[s & 1]
+    hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, M0, n, k, k, buf0, ctl, 0, 0, g0keep);
+    for (int s = 1; s <= n_squarings; ++s) {
+      const double* in = (s & 1) ? buf0 : buf1;
+      double* out = (s & 1) ? buf1 : buf0;
+      hipLaunchKernelGGL(syrk_step_kernel, grid, block, 0, st, in, n, n, n, out, ctl, s, s & 1, (double*)nullptr);
+    }
+    // (a single-workgroup fusion of the finish kernels was measured in round 1: no faster than parallel launches)
+    hipLaunchKernelGGL(rank1_seed_xy_kernel, dim3(ny_blocks + (n + 3) / 4), dim3(256), (size_t)n * sizeof(double), st,
+                       M0, n, k, buf0, (int64_t)(buf1 - buf0), g0keep, ctl, n_squarings & 1, ny_blocks, yv, xv);
+  }
   if (S) {
     const size_t lds = (size_t)(((A + 1) & ~1) + B) * sizeof(double);
     hipLaunchKernelGGL(rank1_final_score_kernel, dim3((unsigned)M), dim3(1024), lds, st, xv, yv, n, k, (A <= B) ? 1 : 0, ctl, wA, wB, info,
-                       S, A, B, tq);
+                       S, A, B, tq, gave);
     return check_launch("rank1_score");
   }
-  hipLaunchKernelGGL(rank1_final_kernel, dim3(1), dim3(1024), 0, st, xv, yv, n, k, (A <= B) ? 1 : 0, ctl, wA, wB, sigma, info);
+  hipLaunchKernelGGL(rank1_final_kernel, dim3(1), dim3(1024), 0, st, xv, yv, n, k, (A <= B) ? 1 : 0, ctl, wA, wB, sigma, info, gave);
   return check_launch("rank1");
 }
 

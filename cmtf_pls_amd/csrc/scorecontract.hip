@@ -172,6 +172,10 @@ constexpr unsigned long long kXchEmpty = ~0ull;
 constexpr int kSplitMaxG = 16;
 constexpr int kSplitSpinLimit = 1 << 21;
 
+__global__ __launch_bounds__(256) void xch_preset_kernel(unsigned long long* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = kXchEmpty;
+}
+
 template <typename T, int NV, bool KC, int LAG>
 __global__ __launch_bounds__(1024) void score_contract_split_kernel(const T* __restrict__ X, int64_t I, unsigned P, int B, int G,
                                                                    const double* __restrict__ wA, const double* __restrict__ wB,
@@ -338,7 +342,7 @@ static int run_score_contract(const T* X, int64_t I, int A, int B, const double*
     double* part = static_cast<double*>(ws);
     double* csum_part = part + (size_t)S * P;
     unsigned long long* xch = reinterpret_cast<unsigned long long*>(csum_part + S);
-    if (hipMemsetAsync(xch, 0xFF, (size_t)I * G * sizeof(double), st) != hipSuccess) return check_launch("score_contract (exchange slots)");
+    hipLaunchKernelGGL(xch_preset_kernel, dim3((unsigned)(((int64_t)I * G + 2047) / 2048)), dim3(256), 0, st, xch, (int64_t)I * G);
 #define SPL(NVV, KCC, LG)                                                                                                          \
   hipLaunchKernelGGL((score_contract_split_kernel<T, NVV, KCC, LG>), dim3(S * G), dim3(1024), 0, st, X, I, (unsigned)P, B, G, wA, wB, \
                      shift, sub_own, add_other, alpha, t, part, csum ? csum_part : nullptr, xch)

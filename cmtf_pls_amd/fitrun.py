@@ -117,6 +117,10 @@ class FitRun(XcovMixin):
             self.status_host = torch.empty(self.status.shape, dtype=torch.float64, pin_memory=True)
         self.sq_max = int(getattr(be, "rank1_squarings", 30))
         self.sq_budget = [self.sq_max] * len(self.blocks)
+        # spare squarings kept above the last extraction's need.  Where the backend runs the squarings as ONE launch (min(J, K) <=
+        # rank1_chain_side: an unused step costs nothing, a missing one a redone iteration) keep three; a launch per squaring: one
+        side = int(getattr(be, "rank1_chain_side", 0))
+        self.sq_spare = [3 if (len(blk.shape) == 3 and min(blk.A, blk.B) <= side) else 1 for blk in self.blocks]
         self.u = be.empty(I)
         self.u_new = be.empty(I)
         self.q = be.empty(M)
@@ -269,6 +273,10 @@ class FitRun(XcovMixin):
         retry = False
         for b in range(len(self.blocks)):
             conv, used = host[1 + 2 * b] > 0.5, int(host[2 + 2 * b])
+            if used < 0:                                             # the one-launch chain gave up (a shared GPU): launches from now on
+                self._chain_gave_up()
+                retry = True
+                continue
             if not conv and self.sq_budget[b] < self.sq_max:
                 self.sq_budget[b] = self.sq_max
                 retry = True
@@ -278,8 +286,35 @@ class FitRun(XcovMixin):
                 # (re-plan only outside [used+1, used+3]) keeps it stable; eager launches follow the need exactly
                 # (every spare launch is ~4 us of an idle GPU)
                 if not self.use_graphs or used + 1 > self.sq_budget[b] or used + 3 < self.sq_budget[b]:
-                    self.sq_budget[b] = min(self.sq_max, used + 1)
+                    self.sq_budget[b] = min(self.sq_max, used + (1 if self.use_graphs else self.sq_spare[b]))
         return retry
+
+    def _peer_failed(self, host, first_attempt: bool) -> bool:
+        """Sharded fits only.  Whether an iteration's tail is redone must be the same decision on every rank (the tail holds a
+        collective).  Everything a rank decides from is a function of all-reduced data -- except the give-up of the one-launch
+        rank-1 chain, which is local.  A rank that gave up leaves NaN loadings, hence a NaN share of Y^T t, hence a NaN q and a NaN
+        convergence norm on EVERY rank after the all-reduce: a rank that sees a non-finite norm on its first attempt therefore
+        redoes the tail too.  Every rank can give up once (it switches its chain off), possibly during somebody else's repeat: a
+        non-finite norm is therefore answered up to world + 1 times per iteration; data that really is non-finite shows again
+        after that and is reported by the fit as before."""
+        if not self.eng.comm.sharded:
+            return False
+        if first_attempt:
+            self._nan_tails = 0
+        if np.isfinite(float(host[0])) or self._nan_tails > int(getattr(self.eng.comm, "world", 1)):
+            return False
+        self._nan_tails += 1
+        return True
+
+    def _chain_gave_up(self) -> None:
+        be = self.eng.be
+        if hasattr(be, "rank1_chain_gave_up"):
+            be.rank1_chain_gave_up()
+        self._graphs.clear()                                         # captured sequences hold the chain kernel
+        self.sq_spare = [1] * len(self.blocks)
+        note = "rank-1 chain of squarings in one launch switched off: a workgroup never became resident (GPU shared with another process)"
+        if note not in self.notes:
+            self.notes.append(note)
 
     def _read_status(self) -> np.ndarray:
         if self.status_host is None:
@@ -395,8 +430,8 @@ class FitRun(XcovMixin):
             if sharded:
                 # |u_old - u|^2 = dq^T (Y^T Y) dq with the all-reduced Gram: no third collective
                 be.rowdot(self.Y, self.q, u_new, None)                           # tpls.py:102
-                if it > 0:
-                    be.quadform(self.Gy, self.q, self.q_prev, self.status[0:1])  # tpls.py:103
+                # tpls.py:103; on the first pass (oldU = inf there) the form with q itself: 0, or NaN when q is -- see _peer_failed
+                be.quadform(self.Gy, self.q, self.q_prev if it > 0 else self.q, self.status[0:1])
             else:
                 be.rowdot(self.Y, self.q, u_new, u if it > 0 else None, du2=self.status[0:1])   # tpls.py:102-103
 
@@ -421,7 +456,8 @@ class FitRun(XcovMixin):
                 comm.allreduce(self.q)
                 self._run(("yupdate", it > 0, par), seg_y_update)
             host = self._read_status()
-            if not self._update_budgets(host):
+            local, peer = self._update_budgets(host), self._peer_failed(host, first)     # (both always evaluated)
+            if not (local or peer):
                 break
             first = False
         if sharded:
@@ -506,7 +542,8 @@ class FitRun(XcovMixin):
                     comm.allreduce(q_new)
                     self._run(("fyupdate", par), seg_y_update)
             host = self._read_status()
-            if not self._update_budgets(host):
+            local, peer = self._update_budgets(host), self._peer_failed(host, first)     # (both always evaluated)
+            if not (local or peer):
                 break
             first = False
         self._parity ^= 1

@@ -153,6 +153,12 @@ class XcovMixin:
                     stats["ahead"] += 1
             host = be.status_wait(tok)
             short = [b for b in range(nb) if not host[1 + 2 * b] > 0.5 and self.sq_budget[b] < self.sq_max]
+            if any(host[2 + 2 * b] < 0 for b in range(nb)):         # the one-launch chain gave up (a shared GPU): launches from now on
+                self._chain_gave_up()
+                pp["plans"].clear()
+                tok = enqueue(it, first=False)
+                stats["redone"] += 1
+                continue
             if short:
                 # a rank-1 extraction ran out of squarings: redo the tail of iteration it with the full budget (Z of set it & 1
                 # is intact; whatever was enqueued ahead was built on the unfinished loadings and is overwritten later)
@@ -163,7 +169,7 @@ class XcovMixin:
                 continue
             for b, blk in enumerate(self.blocks):
                 if len(blk.shape) == 3 and host[1 + 2 * b] > 0.5:
-                    self.sq_budget[b] = min(self.sq_max, int(host[2 + 2 * b]) + 1)
+                    self.sq_budget[b] = min(self.sq_max, int(host[2 + 2 * b]) + self.sq_spare[b])
             self._executed += 1
             stats["iterations"] += 1
             du_prev, du = du, (None if it == 0 else math.sqrt(max(float(host[0]), 0.0)))

@@ -93,11 +93,24 @@ int cmtfpls_colscale_f64(double* Z, int64_t P, const double* colcnt, double n_sa
  * info[0] = 1 if the squaring was seen to converge within n_squarings (else the caller should call
  * again with a larger budget), info[1] = squarings actually computed (budget hint for the next call).
  * Limit: min(A, B) <= 4096 (round 2: 1024), CMTFPLS_EUNSUPPORTED beyond.
+ * Round 4: for min(A, B) <= 256 and n_squarings <= 31 the whole chain of squarings is ONE launch (its (n/16)^2 workgroups stay
+ * resident and pass the 16-row panels of G_s to each other through 8-byte agent-scope stores whose value is their own flag, no
+ * grid barrier, no fence); cmtfpls_rank1_launches_f64 always takes the launch-per-squaring form (same bits: what the tests
+ * compare the chain with).
  * normalize: v /= ||v||_2, the vector case `Z / norm(Z)` (tpls.py:84, cmtf.py:98) and
  * `q /= norm(q)` (tpls.py:101); nrm (nullable) receives the norm. */
 size_t cmtfpls_rank1_workspace_bytes(int A, int B);
 int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
                       int n_squarings, void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_rank1_launches_f64(const double* Z, int A, int B, double* wA, double* wB, double* sigma, double* info,
+                               int n_squarings, void* ws, size_t ws_bytes, void* stream);
+/* The one-launch chain needs all of its workgroups resident at once: true on a GPU the process has to itself.  If a workgroup
+ * waits in vain (tens of milliseconds: several processes sharing the card) the extraction returns NaN loadings and info =
+ * [0, -1]; the caller then switches the chain off for the process (every entry that extracts a rank-1 pair takes the launch
+ * form from then on) and repeats the call.  on = 2 (tests only): the chain runs with one row of its workgroups missing, which
+ * exercises exactly that path. */
+void cmtfpls_rank1_chain_enable(int on);
+int cmtfpls_rank1_chain_enabled(void);
 /* rank1 followed by the score of the M rows of S with the loading just formed, tq[m] = S[m,:] . (wA (x) wB) -- the pair every
  * iteration of the cross-covariance loop issues (tpls.py:84-90, then Y^T t = S w) -- with the extraction's last kernel and the
  * score in ONE launch when S has M <= 64 rows of >= 8192 elements (B even); any other shape runs the two entries one after the

@@ -247,6 +247,40 @@ def test_rank1_close_singular_values_and_zero_rows(be):
     np.testing.assert_allclose(np.linalg.norm(host(wB)), 1, rtol=1e-14)
 
 
+@pytest.mark.parametrize("shape", [(128, 128), (256, 256), (96, 160), (200, 200), (160, 72), (16, 4096), (5, 7), (256, 1000), (40, 30)])
+@pytest.mark.parametrize("budget", [30, 2, 9])
+def test_rank1_chain_of_squarings_in_one_launch_equals_a_launch_per_squaring(be, shape, budget):
+    """Round 4: for min(A, B) <= 256 cmtfpls_rank1_f64 runs the Gram matrix and every squaring in ONE launch (syrk_chain_kernel:
+    resident workgroups passing the panels of G_s to each other through agent-scope stores whose value is their own flag) --
+    bit for bit the loadings, the convergence flag and the squarings used of the launch-per-squaring form
+    (cmtfpls_rank1_launches_f64), also when the budget runs out before convergence (2), with an exact zero row / column in Z
+    (tests/test_tpls.py:98-104) and with the larger side first (Z transposed inside)."""
+    A, B = shape
+    rng = np.random.default_rng(A * 7 + B)
+    n = min(A, B)
+    U, _ = np.linalg.qr(rng.normal(size=(A, n)))
+    V, _ = np.linalg.qr(rng.normal(size=(B, n)))
+    Z = (U * (0.93 ** np.arange(n))) @ V.T
+    Z[A // 2, :] = 0.0
+    Z[:, B // 3] = 0.0
+    Zd = dev(Z.ravel())
+    out = []
+    for launches in (True, False):
+        wA, wB, info = be.empty(A), be.empty(B), be.zeros(2)
+        be.rank1(Zd, A, B, wA, wB, info=info, n_squarings=budget, launches=launches)
+        out.append((host(wA).copy(), host(wB).copy(), host(info).copy()))
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y), (shape, budget, np.abs(x - y).max())
+    assert out[1][0][A // 2] == 0.0 and out[1][1][B // 3] == 0.0
+    if budget == 30:
+        assert out[1][2][0] == 1.0
+        u, v, S = _svd_pair(Z)
+        np.testing.assert_allclose(out[1][0], u, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(out[1][1], v, rtol=0, atol=1e-9)
+    if budget == 2 and n > 8:
+        assert out[1][2][0] == 0.0                          # not converged within two squarings: the caller must ask again
+
+
 def test_small_algebra(be):
     rng = np.random.default_rng(13)
     I, M, R = 1003, 16, 7

@@ -425,3 +425,37 @@ def test_q2y_beyond_the_lds_shapes_equals_literal_refits(api, shape, M, R):
         r.fit(x[keep], y[keep])
         want = r.predict(x[i:i + 1]).reshape(-1)
         assert np.abs(pred[i].reshape(-1) - want).max() <= 1e-8 * max(1.0, np.abs(want).max()), (i, pred[i], want)
+
+
+# ---- the rank-1 chain of squarings in one launch: what happens when its workgroups are not all resident ----------------------------
+def test_rank1_chain_gives_up_loudly_and_the_engine_falls_back_to_launches(api):
+    """syrk_chain_kernel needs every workgroup resident (true on a GPU the process owns).  With one row of workgroups missing
+    (cmtfpls_rank1_chain_enable(2), a test mode) the partners wait a bounded time, the extraction returns info = [0, -1] with
+    NaN loadings -- never a wrong 'converged' -- and the engine switches the chain off for the process, repeats the iteration
+    through the launch-per-squaring form and says so in the report: same fit as with the chain off from the start."""
+    from cmtf_pls_amd.backend import HipBackend
+    be = HipBackend("cuda:0")
+    lib = be.lib
+    x, y, _ = O.import_synthetic((300, 64, 48), 5, 4, error=0.2, seed=9)
+    try:
+        lib.cmtfpls_rank1_chain_enable(0)
+        ref = api.tPLS(3, algorithm="xcov", options=default_options().but(small_fit=False))
+        ref.fit(x, y)
+        # kernel level
+        lib.cmtfpls_rank1_chain_enable(2)
+        Z = torch.randn(64 * 48, dtype=torch.float64, device="cuda:0")
+        wA, wB, info = be.empty(64), be.empty(48), be.zeros(2)
+        be.rank1(Z, 64, 48, wA, wB, info=info)
+        assert info.cpu().tolist() == [0.0, -1.0] and bool(torch.isnan(wA).any())
+        # engine level: direct and xcov
+        for algorithm in ("xcov", "direct"):
+            lib.cmtfpls_rank1_chain_enable(2)
+            be2 = HipBackend("cuda:0")
+            m = api.tPLS(3, algorithm=algorithm, backend=be2, options=default_options().but(small_fit=False))
+            m.fit(x, y)
+            assert lib.cmtfpls_rank1_chain_enabled() == 0
+            assert any("switched off" in d for d in m.fit_report_["declined"]), m.fit_report_["declined"]
+            assert m.n_iter_ == ref.n_iter_
+            assert _normwise(m.X_factors[0], ref.X_factors[0]) <= 1e-9
+    finally:
+        lib.cmtfpls_rank1_chain_enable(1)
