@@ -48,7 +48,35 @@ def parse(counter, outdir):
     return acc
 
 
+def split_rows(out):
+    """--split-rows: the same two passes over tools/split_row_time.py 32768 256 256 (the north-star row, one read: the row split
+    over four workgroups) -> HBM bytes per launch of score_contract_split_kernel against X's 8.59 GB."""
+    scratch = os.path.join(ROOT, "gpurun_out", "pmc_split")
+    xbytes = 32768 * 256 * 256 * 4
+    vals = {}
+    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        outdir = os.path.join(scratch, sub)
+        os.makedirs(outdir, exist_ok=True)
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "p", "--",
+               "python3", os.path.join(ROOT, "tools", "split_row_time.py"), "32768", "256", "256"]
+        with open(os.path.join(outdir, "run.log"), "w") as log:
+            subprocess.run(cmd, check=True, cwd=os.path.join(ROOT, "tools"), env=dict(os.environ, TMPDIR="/tmp"), stdout=log, stderr=subprocess.STDOUT)
+        files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
+        acc = [float(r["Counter_Value"]) * 1024.0 for r in csv.DictReader(open(files[0]))
+               if r["Counter_Name"] == counter and "score_contract_split_kernel<float" in r["Kernel_Name"]]
+        vals[counter] = (sum(acc) / len(acc), len(acc))
+    f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    doc = {"round": ROUND, "workload": "score_contract on 32768x256x256 f32 (tools/split_row_time.py), 1 GPU", "kernel": "score_contract_split_kernel<float, 4, true, 1>",
+           "fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w, "dispatches": vals["FETCH_SIZE"][1],
+           "algorithmic_bytes": xbytes, "ratio": (2 * f + w) / xbytes,
+           "method": "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only); unit KB; FETCH_SIZE doubled (gfx950 note of MI355X_MICROARCH.md)"}
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps({"score_contract_split_kernel": round(doc["ratio"], 4)}))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--split-rows":
+        return split_rows(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "pmc_traffic_split_rows.json"))
     scratch = os.path.join(ROOT, "gpurun_out", "pmc")
     if len(sys.argv) > 1 and sys.argv[1] == "--parse":          # re-parse CSVs collected earlier (no GPU needed)
         out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "pmc_traffic.json")
