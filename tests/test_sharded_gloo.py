@@ -152,3 +152,61 @@ def test_rank1_budget_retry_sharded():
         ret = mgr.dict()
         mp.spawn(_retry_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def _giveup_worker(rank, world, port, ret):
+    """ONE rank's rank-1 extraction gives up (info = [0, -1], NaN loadings: what the one-launch chain of squarings reports when a
+    workgroup never became resident) -- a rank-LOCAL event, unlike everything else an iteration's retry is decided from.  The
+    NaN reaches every rank through the all-reduced Y^T t, so all ranks repeat the tail (FitRun._peer_failed) and the collectives
+    stay matched: same fit as without the incident, on the fused and the unfused direct iteration."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from cmtf_pls_amd import tPLS
+        from cmtf_pls_amd.engine import Comm
+        from numpy_backend import NumpyBackend
+
+        class GivesUp(NumpyBackend):
+            """Rank 1 gives up on its 3rd and rank 0 on its 7th extraction, once each (a rank switches its chain off afterwards)."""
+            calls = 0
+            gave = False
+
+            def rank1(self, Z, A, B, wA, wB, info=None, n_squarings=None):
+                super().rank1(Z, A, B, wA, wB, info=info, n_squarings=n_squarings)
+                self.calls += 1
+                if not self.gave and self.calls == (3 if rank == 1 else 7):
+                    wA.fill_(float("nan"))
+                    wB.fill_(float("nan"))
+                    info[0], info[1] = 0.0, -1.0
+
+            def rank1_chain_gave_up(self):
+                self.gave = True
+
+        for M in (3, 70):                                   # 3: Y side fused into the sweeps; 70: the unfused iteration
+            x, y, _ = O.import_synthetic((60, 8, 6), M, 3, error=0.1, seed=21)
+            rows = slice(rank * 30, (rank + 1) * 30)
+            be = GivesUp()
+            m = tPLS(3, backend=be, comm=Comm())
+            m.fit(x[rows], y[rows])
+            assert be.gave and any("switched off" in d for d in m.fit_report_["declined"])
+            fit = O.fit_tpls(x, y, 3)
+            assert list(m.n_iter_) == list(fit.n_iter)
+            np.testing.assert_allclose(m.X_factors[0], fit.T[rows], rtol=1e-6, atol=1e-8)
+            np.testing.assert_allclose(m.Y_factors[1], fit.Q, rtol=1e-6, atol=1e-8)
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc() + repr(e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_ranks_rank1_chain_gives_up_in_a_sharded_fit():
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_giveup_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
