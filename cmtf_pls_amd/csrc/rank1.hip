@@ -236,16 +236,26 @@ __global__ __launch_bounds__(256) void chain_preset_kernel(unsigned long long* _
 
 // gbufs: (n_squarings + 1) matrices of n x n (G_s at s * n * n); trs: (n_squarings + 1) x nt; fros: (n_squarings + 1) x nt * nt --
 // one contiguous region preset to 0xFF bytes by the caller.
-__global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const double* __restrict__ M0, int n, int k0,
+#ifdef CMTFPLS_CHAIN_PROFILE       // tools/exp builds only: workgroup (0, 0) stamps the phases of every step (100 MHz clock)
+__device__ unsigned long long g_chain_prof[1024];
+#define CHAIN_STAMP(slot) do { if (first_wg && tid == 0 && step < 32) g_chain_prof[step * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CHAIN_COUNT(slot, v) do { if (first_wg && tid == 0 && step < 32) g_chain_prof[step * 8 + (slot)] = (unsigned long long)(v); } while (0)
+#else
+#define CHAIN_STAMP(slot) do { } while (0)
+#define CHAIN_COUNT(slot, v) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kTile* kTile) void syrk_chain_kernel(const double* __restrict__ M0, int n, int k0,
                                                                  double* gbufs, double* trs, double* fros, double* gave_up,
                                                                  Rank1Ctl* __restrict__ ctl, int n_squarings) {
   constexpr int KC = 128, KW = 8, LDP = KC + 2;            // chunk width; columns per lane per chunk; padded panel row in LDS
-  __shared__ double pan[2][kTile][LDP];                    // the two 16-row panels of the current chunk (steps >= 1)
+  __shared__ __attribute__((aligned(16))) double pan[2][kTile][LDP];   // the two 16-row panels of the current chunk (steps >= 1)
   __shared__ double red[2][4][kTile * kTile];              // (by step parity: no barrier between a step's last read and the next step's writes)
   __shared__ double diag[2][kTile];
   __shared__ double fsum[2][4];
-  __shared__ double s_scale[2];
-  __shared__ int s_dec[2];
+  __shared__ double cfro[2][4];                            // control words of the step's input: per-wavefront sums of the tiles' sums of squares,
+  __shared__ double ctr[2][kTile];                         // the diagonal tiles' traces,
+  __shared__ int cdead[2];                                 // and whether a wavefront of this workgroup gave up
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTile + tx;
   const int lane = tid & 63, wv = tid >> 6, ri = lane & 15, kq = lane >> 4;
   const int nt = (n + kTile - 1) / kTile, nt2 = nt * nt;
@@ -257,12 +267,16 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
   const double qnan = __longlong_as_double(0x7FF8000000000000ll);
   bool dead = false;                                       // this wavefront gave up on a partner
   if (first_wg && tid == 0) { ctl->done = 0; ctl->final_buf = -1; ctl->steps_used = 0; ctl->last_step = -1; }
+  if (tid < 2) cdead[tid] = 0;
   // ---- step 0: G_0 = M0 M0^T, operands straight from global memory (Z was written before this launch) ----
   // ---- step s >= 1: the panels of G_{s-1} are fetched by the WHOLE workgroup in coalesced 8-byte agent-scope loads (element
   // e = tid + 256 i of a 16 x 128 chunk: 512 contiguous bytes per instruction -- as MFMA operands straight from memory every
-  // load instruction would touch 64 lines, and un-cached loads are paid per line), each wavefront repeating its own sixteen
-  // while one still shows the preset; then staged through LDS into the MFMA layout.  Wavefront 0 fetches the control words in
-  // the same batch and decides for the workgroup.
+  // load instruction would touch 64 lines, and un-cached loads are paid per line), each wavefront repeating its own batch
+  // while one value still shows the preset; then staged through LDS into the MFMA layout.  The control words ride in the same
+  // batch: wavefront w takes the tiles' sums of squares 64 w .. 64 w + 63, wavefront 0 the traces; after the staging barrier
+  // EVERY thread derives the scale and the exit decisions from the same LDS words, in syrk_step_kernel's orders -- fro = ((w0 +
+  // w1) + w2) + w3 with w_i the butterfly sum of entries 64 i .. 64 i + 63, the trace added in tile order -- while the operands
+  // are on their way from LDS to the matrix cores (one wavefront deciding for all cost 0.6 us of every step).
   int last_step = -1;                                      // (what syrk_step_kernel keeps in ctl->last_step)
   for (int step = 0; step <= n_squarings; ++step) {
     if (last_step >= 0) break;                             // the previous step declared its own output final
@@ -272,7 +286,9 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
     double* C = gbufs + (int64_t)step * nn;
     double a[KW], b[KW];
     double scale = 1.0;
+    bool input_is_result = false;
     d4r_t acc = d4r_t{0.0, 0.0, 0.0, 0.0};
+    CHAIN_STAMP(0);
     for (int kk = 0; kk < k; kk += KC) {
       if (step == 0) {
         const double* __restrict__ rowa = M + (int64_t)(ra ? i0 + ri : 0) * ld;
@@ -285,8 +301,8 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
           b[s2] = rowb[cc];
         }
       } else {
-        double va[8], vb[8], trv = 0.0, f[4] = {0.0, 0.0, 0.0, 0.0};
-        const bool ctl_wave = (wv == 0 && kk == 0);
+        double va[8], vb[8], trv = 0.0, f = 0.0;
+        const bool first_chunk = kk == 0;
         const double* tp = trs + (int64_t)(step - 1) * nt;
         const double* fp = fros + (int64_t)(step - 1) * nt2;
         unsigned offa[8], offb[8];
@@ -306,13 +322,13 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
             va[i] = chain_ld(M + offa[i]);
             vb[i] = chain_ld(M + offb[i]);
           }
-          if (ctl_wave) {
-            trv = chain_ld(tp + ((lane < nt) ? lane : 0));
-#pragma unroll
-            for (int w = 0; w < 4; ++w) f[w] = chain_ld(fp + ((64 * w + lane < nt2) ? 64 * w + lane : 0));
-            ok = !chain_empty(trv);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) ok = ok && !chain_empty(f[w]);
+          if (first_chunk) {
+            f = chain_ld(fp + ((tid < nt2) ? tid : 0));
+            ok = !chain_empty(f);
+            if (wv == 0) {
+              trv = chain_ld(tp + ((lane < nt) ? lane : 0));
+              ok = ok && !chain_empty(trv);
+            }
           }
 #pragma unroll
           for (int i = 0; i < 8; ++i) ok = ok && !chain_empty(va[i]) && !chain_empty(vb[i]);
@@ -323,6 +339,8 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
             break;
           }
         }
+        CHAIN_STAMP(1);
+        CHAIN_COUNT(7, spins);
         if (kk > 0) __syncthreads();                       // the previous chunk's panels have been consumed
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -330,43 +348,37 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
           pan[0][r][c] = dead ? qnan : va[i];
           pan[1][r][c] = dead ? qnan : vb[i];
         }
-        if (ctl_wave) {
-          // scale and exit decisions in syrk_step_kernel's orders: fro = ((w0 + w1) + w2) + w3 with w_i the butterfly sum of entries
-          // 64 i .. 64 i + 63, the trace added in tile order.  (A control wavefront that gave up decides "go on": the chain then
-          // walks to its last step on NaNs.)
-          double fw[4];
-#pragma unroll
-          for (int w = 0; w < 4; ++w) fw[w] = wave_sum((64 * w + lane < nt2) ? f[w] : 0.0);
-          const double fro_in = ((fw[0] + fw[1]) + fw[2]) + fw[3];
+        if (first_chunk) {
+          const double fw = wave_sum((tid < nt2) ? f : 0.0);
+          if (lane == 0) cfro[par][wv] = fw;
+          if (wv == 0 && lane < nt) ctr[par][lane] = trv;
+          if (dead && lane == 0) cdead[par] = 1;
+        }
+        __syncthreads();
+        CHAIN_STAMP(2);
+        if (first_chunk) {
+          // (a workgroup with a wavefront that gave up decides "go on": the chain then walks to its last step on NaNs)
+          const double fro_in = ((cfro[par][0] + cfro[par][1]) + cfro[par][2]) + cfro[par][3];
           double tr1 = 0.0;
-          for (int i = 0; i < nt; ++i) tr1 += __shfl(trv, i, kWave);
-          double sc = 1.0;
+          for (int i = 0; i < nt; ++i) tr1 += ctr[par][i];
           if ((tr1 > 0.0) && isfinite(tr1)) {
             int e;
             frexp(tr1, &e);
-            sc = ldexp(1.0, -e);
+            scale = ldexp(1.0, -e);
           }
+          const bool gone = cdead[par] != 0;
           const double rho = fro_in / (tr1 * tr1);
-          const bool rank_one_in = !dead && (!(tr1 > 0.0) || rho >= 1.0 - 1e-13);     // the input already is the result
-          const bool rank_one_out = !dead && rho >= 1.0 - 1e-7;                        // this step's output will be
-          if (lane == 0) {
-            s_scale[par] = sc;
-            s_dec[par] = rank_one_in ? 1 : (rank_one_out ? 2 : 0);
-            if (first_wg) {
-              if (rank_one_in) { ctl->done = 1; ctl->final_buf = step - 1; }
-              else {
-                ctl->steps_used = step;
-                if (rank_one_out) { ctl->last_step = step; ctl->final_buf = step; }
-              }
+          const bool rank_one_in = !gone && (!(tr1 > 0.0) || rho >= 1.0 - 1e-13);     // the input already is the result
+          const bool rank_one_out = !gone && rho >= 1.0 - 1e-7;                        // this step's output will be
+          if (first_wg && tid == 0) {
+            if (rank_one_in) { ctl->done = 1; ctl->final_buf = step - 1; }
+            else {
+              ctl->steps_used = step;
+              if (rank_one_out) { ctl->last_step = step; ctl->final_buf = step; }
             }
           }
-        }
-        __syncthreads();
-        if (kk == 0) {
-          const int dec = s_dec[par];
-          if (dec == 1) break;
-          if (dec == 2) last_step = step;
-          scale = s_scale[par];
+          if (rank_one_in) { input_is_result = true; break; }
+          if (rank_one_out) last_step = step;
         }
 #pragma unroll
         for (int s2 = 0; s2 < KW; ++s2) {
@@ -382,14 +394,19 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
     }
-    if (step >= 1 && s_dec[par] == 1) break;               // (left the chunk loop through the decision: the input is the result)
+    if (input_is_result) break;
+    CHAIN_STAMP(3);
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[par][wv][(kq + 4 * e) * kTile + ri] = acc[e];
     __syncthreads();
+    CHAIN_STAMP(4);
     double cacc = ((red[par][0][tid] + red[par][1][tid]) + red[par][2][tid]) + red[par][3][tid];
     cacc *= scale * scale;
     const bool inside = (i0 + ty < n && j0 + tx < n);
+    // (the tile goes out first: moving its stores behind the barrier below -- which waits for them -- made a step slower, and so
+    // did limiting the registers for three workgroups per CU: 54 / 57 / 63 us per extraction, profiles/r04w_chain_variants.txt)
     if (inside) chain_st(C + (int64_t)(i0 + ty) * n + (j0 + tx), cacc);
+    CHAIN_STAMP(5);
     double sq = inside ? cacc * cacc : 0.0;
     sq = wave_sum(sq);
     if ((tid & 63) == 0) fsum[par][tid >> 6] = sq;
@@ -403,6 +420,7 @@ __global__ __launch_bounds__(kTile* kTile, 3) void syrk_chain_kernel(const doubl
         chain_st(trs + (int64_t)step * nt + blockIdx.x, t);
       }
     }
+    CHAIN_STAMP(6);
   }
 }
 
@@ -680,6 +698,9 @@ int cmtfpls_rank1_f64(const double* Z, int A, int B, double* wA, double* wB, dou
   return rank1_run(Z, A, B, wA, wB, sigma, info, n_squarings, ws, ws_bytes, stream, nullptr, 0, nullptr);
 }
 
+#ifdef CMTFPLS_CHAIN_PROFILE
+int cmtfpls_debug_chain_prof(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_prof), sizeof(unsigned long long) * 1024); }
+#endif
 void cmtfpls_rank1_chain_enable(int on) { g_chain_on.store((on == 1 || on == 2) ? on : 0, std::memory_order_relaxed); }
 int cmtfpls_rank1_chain_enabled(void) { return g_chain_on.load(std::memory_order_relaxed); }
 
