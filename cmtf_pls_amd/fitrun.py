@@ -778,5 +778,9 @@ class FitRun(XcovMixin):
                 self.notes.append("one read per component declined: the row does not fit the registers of 1..16 workgroups "
                                   "(rows of 2048..131072 f32 -- 262144 when the last mode divides 4096 -- / 1024..131072 f64 elements, "
                                   "last mode a multiple of 4 / 2)")
+        # the rank-1 extraction of order-3 blocks with min(J, K) <= 256: every Gram squaring in one launch, unless the process had to
+        # switch that off (a GPU shared with another process)
+        rep["rank1_one_launch_chain"] = bool(getattr(eng.be, "rank1_chain_side", 0)) and any(
+            len(blk.shape) == 3 and min(blk.A, blk.B) <= int(getattr(eng.be, "rank1_chain_side", 0)) for blk in self.blocks)
         rep["declined"] = list(self.notes)
         return rep

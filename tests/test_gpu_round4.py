@@ -441,6 +441,12 @@ def test_rank1_chain_gives_up_loudly_and_the_engine_falls_back_to_launches(api):
         lib.cmtfpls_rank1_chain_enable(0)
         ref = api.tPLS(3, algorithm="xcov", options=default_options().but(small_fit=False))
         ref.fit(x, y)
+        assert ref.fit_report_["rank1_one_launch_chain"] is False
+        lib.cmtfpls_rank1_chain_enable(1)
+        on = api.tPLS(3, algorithm="xcov", backend=HipBackend("cuda:0"), options=default_options().but(small_fit=False))
+        on.fit(x, y)
+        assert on.fit_report_["rank1_one_launch_chain"] is True and on.n_iter_ == ref.n_iter_
+        assert np.array_equal(on.X_factors[0], ref.X_factors[0])            # the chain and the launches: the same bits
         # kernel level
         lib.cmtfpls_rank1_chain_enable(2)
         Z = torch.randn(64 * 48, dtype=torch.float64, device="cuda:0")
@@ -455,6 +461,7 @@ def test_rank1_chain_gives_up_loudly_and_the_engine_falls_back_to_launches(api):
             m.fit(x, y)
             assert lib.cmtfpls_rank1_chain_enabled() == 0
             assert any("switched off" in d for d in m.fit_report_["declined"]), m.fit_report_["declined"]
+            assert m.fit_report_["rank1_one_launch_chain"] is False
             assert m.n_iter_ == ref.n_iter_
             assert _normwise(m.X_factors[0], ref.X_factors[0]) <= 1e-9
     finally:
