@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kTile* kTile) void syrk_step_kernel(const double* _
 // matrix work (profiles/r04o_*).  Here the (n/16)^2 workgroups of the step kernel stay resident (n <= 256: at most 256 workgroups
 // of 256 threads) and walk steps 0 .. n_squarings themselves.  What a step needs from the other workgroups -- two 16-row panels
 // of G_{s-1}, the diagonal tiles' traces, every tile's sum of squares -- is passed WITHOUT a grid barrier and without release
-// fences: each G_s has its own buffer, preset to an all-ones pattern no product yields (one memset per extraction), every element
+// fences: each G_s has its own buffer, preset to an all-ones pattern no product yields (one preset launch per extraction), every element
 // is written with an 8-byte agent-scope store and IS its own flag; a consumer simply loads its MFMA operands with agent-scope
 // loads (which by-pass the XCD's L2: measured one-way 0.4 us, tools/exp/xch_latency.hip) and repeats the batch while a lane still
 // sees the preset.  Same tile arithmetic, same summation orders, same control decisions as syrk_step_kernel -- every workgroup
