@@ -296,9 +296,9 @@ def north_star_leg(be, eng_cls, device, steps, repeats, timer):
             break
     out["fit_xcov"] = {"seconds": secs[1], "first_call_seconds": secs[0], "n_iter": list(sx.n_iter),
                        "R2X_final": float(sx.blocks[0].r2x[-1]), "R2Y_final": float(sx.r2y[-1]),
-                       "x_reads_in_all": (R + 2) if rep.get("one_read") else 2 * R + 1,
-                       "floor_s_at_the_read_ceiling": ((R + 2) if rep.get("one_read") else 2 * R + 1) * xbytes / 6.95e12,
-                       "path": {k: rep.get(k) for k in ("algorithm", "raw", "x_copy", "x_written", "one_read", "x_passes_per_component",
+                       "x_reads_in_all": ((R + 2) if rep.get("one_read") else 2 * R + 1) - (1 if rep.get("stats_with_s") else 0),
+                       "floor_s_at_the_read_ceiling": (((R + 2) if rep.get("one_read") else 2 * R + 1) - (1 if rep.get("stats_with_s") else 0)) * xbytes / 6.95e12,
+                       "path": {k: rep.get(k) for k in ("algorithm", "raw", "x_copy", "x_written", "one_read", "stats_with_s", "x_passes_per_component",
                                                         "pipelined", "declined")}}
     del X, Y, Yf, sx
     torch.cuda.empty_cache()

@@ -68,6 +68,9 @@ SIGNATURES = {
     "cmtfpls_axpy_scalar_f64": (c_int, [_P, c_int64, _P, _P, _P]),
     "cmtfpls_xcov_deflate_f32": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_xcov_deflate_f64": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_xcov_stats_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "cmtfpls_xcov_stats_f32": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "cmtfpls_xcov_stats_f64": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_xcov_ssq_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "cmtfpls_xcov_ssq_f32": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "cmtfpls_xcov_ssq_f64": (c_int, [_P, c_int64, c_int64, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),

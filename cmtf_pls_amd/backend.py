@@ -214,6 +214,21 @@ class HipBackend:
                                             self._stream()), "xcov_ssq")
         return out, ssq
 
+    def xcov_stats(self, X2: torch.Tensor, Y: torch.Tensor, out: torch.Tensor):
+        """S = Y^T X_(0) AND the column sums / sums of squares of an uncentred X from ONE read (cmtfpls_xcov_stats_*): returns
+        (S, stats) with stats[:P] the sums and stats[P:] the sums of squares, or None for more than 64 responses."""
+        I, P = X2.shape
+        M = Y.shape[1]
+        if M > 64 or not X2.is_contiguous():
+            return None
+        ws = self._workspace("contract", self.lib.cmtfpls_xcov_stats_workspace_bytes(I, P, M))
+        stats = self.empty(2 * P)
+        rc = self._fn("xcov_stats", X2)(_ptr(X2), I, P, _ptr(Y), Y.stride(0), M, _ptr(out), _ptr(stats), _ptr(ws), ws.numel(), self._stream())
+        if rc == 4:
+            return None
+        _lib.check(rc, "xcov_stats")
+        return out, stats
+
     def status_snapshot(self, status: torch.Tensor, slot: int, slots: Optional[dict] = None):
         """Enqueue a copy of a few status words to pinned host memory behind the work issued so far (cmtfpls_status_to_host);
         returns a token for status_wait.  (slot: the caller keeps at most one snapshot per slot in flight.)  `slots`: the

@@ -47,7 +47,11 @@ XcovPlan plan_xcov(int64_t I, int64_t P) {
 // for a fit that runs on the caller's UNCENTRED tensor (engine.FitRun.raw): the f64 value of every element is formed for the
 // MFMA anyway, so it costs a subtraction and an fma per element and saves the separate pass (cmtfpls_recon_r2_* against a zero
 // reconstruction).  One partial per wavefront, summed in index order by sum_kernel.
-template <typename T, bool MASKED, bool VEC, int MT, bool FAST, bool SSQ = false>
+// STATS (round 4): the same read of X also gives every column's sum and sum of squares (one add and one fma per element on values
+// the MFMA needs anyway) -- the statistics pass of tpls.py:61-71 for a block WITHOUT missing values (a NaN shows in its column's
+// sum), so that a fit on the uncentred tensor reads X once before its first component instead of twice.  Per row block one
+// partial row of 2 P doubles [sums | sums of squares] at ssq_part, summed in block order by reduce_rows_kernel.
+template <typename T, bool MASKED, bool VEC, int MT, bool FAST, bool SSQ = false, bool STATS = false>
 __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int64_t I, int64_t P,
                                                   const double* __restrict__ Y, int ldy, int M,
                                                   double* __restrict__ part, int rows_per_block,
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) ycol[mt] = mok[mt] ? mt * 16 + nn : M - 1;
   double mu[SSQ ? 4 : 1], ssq = 0.0;
+  double cs[STATS ? 4 : 1] = {}, cq[STATS ? 4 : 1] = {};
   if constexpr (SSQ) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) mu[e] = mean[(c + e < P) ? c + e : P - 1];
@@ -117,6 +122,10 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
           const double dv = (FAST || (rok && c + e < P)) ? b - mu[e] : 0.0;
           ssq = fma(dv, dv, ssq);
         }
+        if constexpr (STATS) {
+          cs[e] += b;
+          cq[e] = fma(b, b, cq[e]);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           acc[mt][e] = __builtin_amdgcn_mfma_f64_16x16x4f64((FAST || (rok && mok[mt])) ? a[s][mt] : 0.0, b, acc[mt][e], 0, 0, 0);
@@ -137,6 +146,18 @@ __global__ __launch_bounds__(256) void xcov_kernel(const T* __restrict__ X, int6
   if constexpr (SSQ) {
     ssq = wave_sum(ssq);
     if (lane == 0) ssq_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv] = ssq;
+  }
+  if constexpr (STATS) {                                 // the four lane groups hold the same columns for different rows
+    double* srow = ssq_part + (int64_t)blockIdx.y * 2 * P;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double v = cs[e], w = cq[e];
+      v += __shfl_xor(v, 16, kWave);
+      v += __shfl_xor(v, 32, kWave);
+      w += __shfl_xor(w, 16, kWave);
+      w += __shfl_xor(w, 32, kWave);
+      if (kq == 0 && c + e < P) { srow[c + e] = v; srow[P + c + e] = w; }
+    }
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -274,11 +295,14 @@ static size_t xcov_ssq_extra(const XcovPlan& p) { return ((size_t)p.row_blocks *
 
 template <typename T>
 static int run_xcov_tile(const T* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, int masked,
-                         void* ws, size_t ws_bytes, hipStream_t st, const double* mean = nullptr, double* ssq_out = nullptr) {
+                         void* ws, size_t ws_bytes, hipStream_t st, const double* mean = nullptr, double* ssq_out = nullptr,
+                         double* stats_out = nullptr) {
   const XcovPlan p = plan_xcov(I, P);
-  const bool with_ssq = ssq_out != nullptr;
+  const bool with_ssq = ssq_out != nullptr, with_stats = stats_out != nullptr;
   if (with_ssq && (masked || !mean)) { set_error("xcov_ssq: needs the column means and a block without missing values"); return CMTFPLS_EINVAL; }
-  const size_t need = (size_t)p.row_blocks * M * P * sizeof(double) + (with_ssq ? xcov_ssq_extra(p) : 0);
+  if (with_stats && (masked || with_ssq)) { set_error("xcov_stats: a block without missing values, no second norm"); return CMTFPLS_EINVAL; }
+  const size_t need = (size_t)p.row_blocks * M * P * sizeof(double) + (with_ssq ? xcov_ssq_extra(p) : 0) +
+                      (with_stats ? (size_t)p.row_blocks * 2 * P * sizeof(double) : 0);
   if (!ws || ws_bytes < need) { set_error("xcov: workspace too small"); return CMTFPLS_EWORKSPACE; }
   const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & (4 * sizeof(T) - 1)) == 0);
   const int mt = (M + 15) / 16;                          // 1, 2, 3 -> 4, 4
@@ -286,19 +310,25 @@ static int run_xcov_tile(const T* X, int64_t I, int64_t P, const double* Y, int 
   const dim3 grid(p.col_tiles, p.row_blocks), block(256);
   const bool fast = vec && (P % 256 == 0) && (M % 16 == 0) && (M / 16 != 3) && (I % p.rows_per_block == 0) &&
                     (p.rows_per_block % (8 * 4) == 0);
-  double* ssq_part = with_ssq ? reinterpret_cast<double*>(static_cast<char*>(ws) + (size_t)p.row_blocks * M * P * sizeof(double)) : nullptr;
+  double* ssq_part = (with_ssq || with_stats) ? reinterpret_cast<double*>(static_cast<char*>(ws) + (size_t)p.row_blocks * M * P * sizeof(double)) : nullptr;
 #define XL(MSK, VC, MTT, FS) hipLaunchKernelGGL((xcov_kernel<T, MSK, VC, MTT, FS>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block, (const double*)nullptr, (double*)nullptr)
 #define XS(VC, MTT, FS) hipLaunchKernelGGL((xcov_kernel<T, false, VC, MTT, FS, true>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block, mean, ssq_part)
 #define XM(MSK, VC, FS) do { if (mt == 1) XL(MSK, VC, 1, FS); else if (mt == 2) XL(MSK, VC, 2, FS); else XL(MSK, VC, 4, FS); } while (0)
 #define XQ(VC, FS) do { if (mt == 1) XS(VC, 1, FS); else if (mt == 2) XS(VC, 2, FS); else XS(VC, 4, FS); } while (0)
-  if (with_ssq)    { if (fast) XQ(true, true); else if (vec) XQ(true, false); else XQ(false, false); }
+#define XT1(VC, MTT, FS) hipLaunchKernelGGL((xcov_kernel<T, false, VC, MTT, FS, false, true>), grid, block, 0, st, X, I, P, Y, ldy, M, part, p.rows_per_block, (const double*)nullptr, ssq_part)
+#define XT(VC, FS) do { if (mt == 1) XT1(VC, 1, FS); else if (mt == 2) XT1(VC, 2, FS); else XT1(VC, 4, FS); } while (0)
+  if (with_stats)  { if (fast) XT(true, true); else if (vec) XT(true, false); else XT(false, false); }
+  else if (with_ssq) { if (fast) XQ(true, true); else if (vec) XQ(true, false); else XQ(false, false); }
   else if (masked) { if (fast) XM(true, true, true); else if (vec) XM(true, true, false); else XM(true, false, false); }
   else             { if (fast) XM(false, true, true); else if (vec) XM(false, true, false); else XM(false, false, false); }
+#undef XT
+#undef XT1
 #undef XQ
 #undef XM
 #undef XS
 #undef XL
   launch_reduce_rows(part, p.row_blocks, (int64_t)M * P, S, st);
+  if (with_stats) launch_reduce_rows(ssq_part, p.row_blocks, 2 * P, stats_out, st);
   int rc = check_launch("xcov");
   if (rc == CMTFPLS_OK && with_ssq) rc = cmtfpls_sum_f64(ssq_part, (int64_t)p.row_blocks * p.col_tiles * 4, ssq_out, st);
   return rc;
@@ -384,6 +414,23 @@ int cmtfpls_xcov_ssq_f64(const double* X, int64_t I, int64_t P, const double* Y,
                          double* ssq, void* ws, size_t ws_bytes, void* stream) {
   if (!mean || !ssq) { set_error("xcov_ssq: bad argument"); return CMTFPLS_EINVAL; }
   return run_xcov<double>(X, I, P, Y, ldy, M, S, 0, ws, ws_bytes, (hipStream_t)stream, mean, ssq);
+}
+size_t cmtfpls_xcov_stats_workspace_bytes(int64_t I, int64_t P, int M) {
+  if (I <= 0 || P <= 0 || M <= 0 || M > kXcovMaxResponses) return 0;
+  const XcovPlan p = plan_xcov(I, P);
+  return (size_t)p.row_blocks * ((size_t)M + 2) * P * sizeof(double);
+}
+int cmtfpls_xcov_stats_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, double* stats,
+                           void* ws, size_t ws_bytes, void* stream) {
+  if (!X || !Y || !S || !stats || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov_stats: bad argument"); return CMTFPLS_EINVAL; }
+  if (M > kXcovMaxResponses) { set_error("xcov_stats: more than 64 responses; use colstats + xcov"); return CMTFPLS_EUNSUPPORTED; }
+  return run_xcov_tile<float>(X, I, P, Y, ldy, M, S, 0, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, stats);
+}
+int cmtfpls_xcov_stats_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, double* stats,
+                           void* ws, size_t ws_bytes, void* stream) {
+  if (!X || !Y || !S || !stats || I <= 0 || P <= 0 || M <= 0 || ldy < M) { set_error("xcov_stats: bad argument"); return CMTFPLS_EINVAL; }
+  if (M > kXcovMaxResponses) { set_error("xcov_stats: more than 64 responses; use colstats + xcov"); return CMTFPLS_EUNSUPPORTED; }
+  return run_xcov_tile<double>(X, I, P, Y, ldy, M, S, 0, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, stats);
 }
 int cmtfpls_xcov_deflate_f32(float* X, int64_t I, int A, int B, const double* Y, int ldy, int M, const double* t, const double* wA,
                              const double* wB, double* S, double* ssq, void* ws, size_t ws_bytes, void* stream) {

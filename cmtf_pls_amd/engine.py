@@ -143,6 +143,23 @@ class NipalsEngine(ProjectionMixin):
             worst = ratio if not ratio <= worst else worst          # (a NaN ratio wins: the caller then declines)
         return worst
 
+    def _probe_plain(self, Xs: List[torch.Tensor], limit: float = 100.0) -> bool:
+        """<= 256 rows strided over this rank's shard of every block: no non-finite value among them and max|sample mean| / rms
+        spread <= limit.  What FitRun asks before it takes the column statistics out of the read that builds S (the sums of
+        squares lose ~ratio^2 * 1e-16 there; missing values need the masked statistics anyway).  All-reduced: one decision."""
+        flag = torch.zeros(2, dtype=torch.float64, device=Xs[0].device)
+        for X in Xs:
+            I = X.shape[0]
+            sample = X.view(I, -1)[:: max(1, I // 256)][:256].to(torch.float64)
+            m = sample.mean(dim=0)
+            d = sample - m
+            spread = torch.sqrt((d * d).mean())
+            bad = (~torch.isfinite(sample)).any().to(torch.float64)
+            ratio = torch.where(spread > 0, m.abs().max() / spread, torch.zeros_like(spread))
+            flag += torch.stack([bad, (torch.nan_to_num(ratio, nan=float("inf"), posinf=float("inf")) > limit).to(torch.float64)])
+        self.comm.allreduce(flag)
+        return not bool((flag > 0).any().item())
+
     def _rank1(self, blk: BlockState, Z: torch.Tensor, wA: torch.Tensor, wB: torch.Tensor,
                info: Optional[torch.Tensor] = None, n_squarings: Optional[int] = None,
                fac: Optional[torch.Tensor] = None, tol: float = 1e-8) -> None:

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .fitrun_xcov import XcovMixin
-from .state import FitState, validate_limits
+from .state import BlockState, FitState, split_trailing, validate_limits
 
 
 class FitRun(XcovMixin):
@@ -55,11 +55,31 @@ class FitRun(XcovMixin):
             for b in range(len(Xs)):
                 if not owned[b]:
                     Xs[b] = Xs[b].clone()                        # the fit centres and deflates in place: never the caller's tensor
-        self.blocks = [eng._prepare_block(X, self.n_total, defer_centring=want_raw) for X in Xs]
+        # the responses first (tpls.py:67-68: nothing of it depends on X): the cross-covariance of a candidate for the uncentred
+        # form is taken in the same read as its column statistics, and that needs the centred Y
+        ysum, ycnt = be.colstats(Y)
+        comm.allreduce(ysum)
+        comm.allreduce(ycnt)
+        self.y_mean = ysum / ycnt                                 # tpls.py:67
+        _, ssqy0 = be.center(Y, self.y_mean, False)
+        comm.allreduce(ssqy0)
+        self.ssqy0 = float(ssqy0.item())
         # |X - X_mean|^2 of an uncentred block: from the read that builds S for the first component (backend.xcov_ssq),
         # else from a read of its own (_ssq_uncentred)
         self._ssq_with_s = (want_raw and hasattr(be, "xcov_ssq") and eng.opt.xcov_ssq_with_s)
         self._ssq0_dev = {}
+        self._s_prebuilt = {}                                     # block -> this rank's S = X^T Y_c from the statistics read
+        self.blocks = None
+        self._stats_with_s = False
+        if (want_raw and self._ssq_with_s and eng.opt.xcov_stats_with_s and hasattr(be, "xcov_stats") and M <= 64
+                and eng._probe_plain(Xs)):
+            self.blocks = self._blocks_from_one_read(Xs)
+            self._stats_with_s = self.blocks is not None
+            if self.blocks is None:                               # a missing / non-finite value after all: the statistics pass proper
+                self._s_prebuilt, self._ssq0_dev = {}, {}
+                self.notes.append("column statistics from the read that builds S declined: a column sum came out non-finite")
+        if self.blocks is None:
+            self.blocks = [eng._prepare_block(X, self.n_total, defer_centring=want_raw) for X in Xs]
         self.raw = want_raw and not any(blk.has_miss for blk in self.blocks)
         if self.raw:
             # the uncentred form subtracts mean-sized terms from data-sized results: beyond ~1e4 x the spread it loses digits
@@ -75,14 +95,9 @@ class FitRun(XcovMixin):
                 if not owned[b]:
                     Xs[b] = Xs[b].clone()
                 eng._centre_block(blk, Xs[b])
+        if want_raw and not self.raw:                            # (an S taken from the uncentred tensor serves the uncentred form only)
+            self._s_prebuilt, self._ssq0_dev, self._stats_with_s = {}, {}, False
         self.X2 = [X.view(I, -1) for X in Xs]
-        ysum, ycnt = be.colstats(Y)
-        comm.allreduce(ysum)
-        comm.allreduce(ycnt)
-        self.y_mean = ysum / ycnt                                 # tpls.py:67
-        _, ssqy0 = be.center(Y, self.y_mean, False)
-        comm.allreduce(ssqy0)
-        self.ssqy0 = float(ssqy0.item())
         self.T = be.zeros(I, R)
         self.U = be.zeros(I, R)
         self.Q = be.zeros(M, R)
@@ -166,7 +181,8 @@ class FitRun(XcovMixin):
                     self.S2.append(both[M:])
                 else:
                     self.S12.append(None)
-                    self.S.append(be.empty(M, blk.A * blk.B))
+                    pre = self._s_prebuilt.get(len(self.S))
+                    self.S.append(pre if pre is not None else be.empty(M, blk.A * blk.B))
                     self.S2.append(be.empty(M, blk.A * blk.B) if blk.has_miss else None)
             self.rowscale = [(float(blk.A * blk.B) / blk.rowcnt) if blk.has_miss else None for blk in self.blocks]
             any_miss = any(blk.has_miss for blk in self.blocks)
@@ -210,6 +226,33 @@ class FitRun(XcovMixin):
                         self.csum = be.empty(1)
             assert self._nowrite or not self.raw, "an uncentred X needs the form of the loop that never writes it"
 
+    def _blocks_from_one_read(self, Xs: List[torch.Tensor]) -> Optional[List[BlockState]]:
+        """tpls.py:61-71 for candidates of the uncentred cross-covariance form: ONE read of every block gives its S = X^T Y_c
+        (kept for the first component), its column sums (the means) and its column sums of squares (|X - X_mean|^2 = sum_c
+        sumsq_c - sum_c^2 / n) -- backend.xcov_stats.  None when a sum is non-finite (missing or infinite values: the regular
+        statistics pass decides what to do with them) or the backend declines the shape."""
+        be, comm = self.eng.be, self.eng.comm
+        blocks, n = [], float(self.n_total)
+        for b, X in enumerate(Xs):
+            I = X.shape[0]
+            X2 = X.view(I, -1)
+            P = X2.shape[1]
+            out = be.xcov_stats(X2, self.Y, out=be.empty(self.M, P))
+            if out is None:
+                return None
+            S, stats = out
+            comm.allreduce(stats)
+            colsum, colsq = stats[:P], stats[P:]
+            ssq = (colsq - colsum * colsum / n).sum().reshape(1)
+            if not bool(torch.isfinite(ssq).all().item()):
+                return None
+            A, B = split_trailing(X.shape)
+            blocks.append(BlockState(shape=tuple(X.shape), A=A, B=B, mean=colsum / n, has_miss=False, colcnt=None, rowcnt=None,
+                                     ssq0=float("nan"), dtype=X.dtype))
+            self._s_prebuilt[b] = S
+            self._ssq0_dev[b] = ssq                               # (summed over the ranks already: the statistics were)
+        return blocks
+
     def start_component(self, a: int) -> None:
         self._executed = 0
         be, comm = self.eng.be, self.eng.comm
@@ -232,7 +275,9 @@ class FitRun(XcovMixin):
                 be.xcov(self.X2[b], self.Yw, True, out=self.S12[b], mixed=self.mixed)
                 comm.allreduce(self.S12[b])
                 continue
-            if self.raw and self._ssq_with_s and b not in self._ssq0_dev:
+            if b in self._s_prebuilt:                             # S and the statistics came from ONE read, in __init__
+                del self._s_prebuilt[b]
+            elif self.raw and self._ssq_with_s and b not in self._ssq0_dev:
                 _, ssq = be.xcov_ssq(self.X2[b], self.Y, blk.mean, out=self.S[b])   # S and |X - X_mean|^2 from one read
                 self._ssq0_dev[b] = comm.allreduce(ssq)                       # (read back in result(), with everything else)
             else:
@@ -755,6 +800,9 @@ class FitRun(XcovMixin):
                              (f", {(self.M + 63) // 64} response tiles of <= 64" if self.M > 64 else "") + \
                              (", [Y, Y * rowscale] in one pass" if any(x is not None for x in self.S12) else "")
             rep["one_read"] = one_read
+            # the column statistics (tpls.py:61-71) out of the read that builds S for the first component: X is read once, not twice,
+            # before the first inner loop
+            rep["stats_with_s"] = bool(getattr(self, "_stats_with_s", False))
             if nowrite:
                 rep["x_passes_per_component"] = ("1 read (largest block); 2 reads (other blocks)" if one_read and nb > 1 else
                                                  "1 read" if one_read else "2 reads")

@@ -33,6 +33,9 @@ class EngineOptions:
     # a fit on the uncentred tensor: |X - X_mean|^2 from the read that builds S for the first component instead of a read of
     # its own (backend.xcov_ssq); False keeps the separate pass
     xcov_ssq_with_s: bool = True
+    # ... and the statistics pass too: column sums and sums of squares from the read that builds S for the first component
+    # (backend.xcov_stats): a fit on the uncentred tensor reads X once before its first component; False keeps colstats first
+    xcov_stats_with_s: bool = True
     # one block WITH missing values: the deflation happens inside the rebuild of S for the next component (one read + write
     # of X instead of a read + write and a read, FitRun._finish_xcov_masked_fused); False keeps the two passes
     xcov_deflate_build: bool = True

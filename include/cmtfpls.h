@@ -157,6 +157,15 @@ int cmtfpls_xcov_deflate_f64(double* X, int64_t I, int A, int B, const double* Y
  * UNCENTRED X without missing values: |X - X_mean|^2, the denominator of R2X (util.py:7-20, tpls.py:115-117), for the fit that
  * never centres, writes or copies X.  (The f64 value of every element is formed for the matrix cores anyway.) */
 size_t cmtfpls_xcov_ssq_workspace_bytes(int64_t I, int64_t P, int M);
+/* xcov_stats (round 4): S as cmtfpls_xcov_* (unmasked, M <= 64) AND the statistics pass of tpls.py:61-71 from the same read of an
+ * uncentred X: stats[0..P) = the column sums, stats[P..2P) = the column sums of squares (a missing value shows as a NaN in its
+ * column's sum: the caller then takes cmtfpls_colstats_* and the masked forms).  With them mean = sum / I and
+ * |X - X_mean|^2 = sum_c (sumsq_c - sum_c^2 / I): a fit on the uncentred tensor reads X ONCE before its first component. */
+size_t cmtfpls_xcov_stats_workspace_bytes(int64_t I, int64_t P, int M);
+int cmtfpls_xcov_stats_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, double* stats,
+                           void* ws, size_t ws_bytes, void* stream);
+int cmtfpls_xcov_stats_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, double* stats,
+                           void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_xcov_ssq_f32(const float* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, const double* mean,
                          double* ssq, void* ws, size_t ws_bytes, void* stream);
 int cmtfpls_xcov_ssq_f64(const double* X, int64_t I, int64_t P, const double* Y, int ldy, int M, double* S, const double* mean,

@@ -137,6 +137,13 @@ class NumpyBackend:
         out.copy_(torch.from_numpy(_np(Y).T @ x))
         return out, torch.tensor([float(((x - _np(mean)) ** 2).sum())], dtype=torch.float64)
 
+    def xcov_stats(self, X2, Y, out):
+        if Y.shape[1] > 64:
+            return None
+        x = _np(X2).astype(np.float64)
+        out.copy_(torch.from_numpy(_np(Y).T @ x))
+        return out, torch.from_numpy(np.concatenate([x.sum(axis=0), (x * x).sum(axis=0)]))
+
     def xcov_deflate(self, X2, A, B, Y, t, wA, wB, out):
         if X2.shape[1] % 4 != 0 or Y.shape[1] > 64:
             return None        # (the HIP kernel takes whole 4-element vectors only: the engine must deflate, then rebuild)

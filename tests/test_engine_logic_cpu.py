@@ -320,11 +320,14 @@ def test_xcov_one_read_per_component_equals_two_reads(case, monkeypatch):
     np.testing.assert_allclose(one.coef_[:ncmp, :ncmp], two.coef_[:ncmp, :ncmp], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("stats_with_s", [True, False])
 @pytest.mark.parametrize("case", ["tpls3", "coupled", "matrix"])
-def test_xcov_on_the_uncentred_tensor_equals_the_centred_form_cpu(case, monkeypatch):
+def test_xcov_on_the_uncentred_tensor_equals_the_centred_form_cpu(case, stats_with_s, monkeypatch):
     """NipalsEngine.xcov_raw through the NumPy backend: the fit reads the caller's uncentred blocks (never written, never centred)
-    and applies the centring algebraically; |X - X_mean|^2 comes out of the S-build read (xcov_ssq).  Same fit as on centred copies."""
-    opt = {}                                              # EngineOptions fields this test overrides
+    and applies the centring algebraically; |X - X_mean|^2 comes out of the S-build read (xcov_ssq) -- and since round 4 the
+    column statistics too (xcov_stats: ONE read of a block before its first component; stats_with_s = False keeps the
+    statistics pass and xcov_ssq).  Same fit as on centred copies."""
+    opt = {"xcov_stats_with_s": stats_with_s}             # EngineOptions fields this test overrides
     import torch
     rng = np.random.default_rng(5)
     x, y, cp = O.import_synthetic((40, 6, 5), 3, 3, error=0.2, seed=8)
@@ -332,7 +335,7 @@ def test_xcov_on_the_uncentred_tensor_equals_the_centred_form_cpu(case, monkeypa
     xm = cp.factors[0] @ rng.normal(size=(7, 3)).T - 2.0
     blocks = {"tpls3": [x], "coupled": [x, xm], "matrix": [xm]}[case]
     coupled = len(blocks) > 1
-    calls = {"xcov_ssq": 0, "center": 0}
+    calls = {"xcov_ssq": 0, "xcov_stats": 0, "center": 0, "colstats": 0}
     for name in calls:
         orig = getattr(NumpyBackend, name)
 
@@ -349,7 +352,11 @@ def test_xcov_on_the_uncentred_tensor_equals_the_centred_form_cpu(case, monkeypa
         return m, held
 
     raw, held = fit(True)
-    assert calls["xcov_ssq"] == len(blocks) and calls["center"] == 1          # (the one centring call is Y's)
+    assert calls["center"] == 1                                                # (the one centring call is Y's)
+    if stats_with_s:
+        assert calls["xcov_stats"] == len(blocks) and calls["xcov_ssq"] == 0 and raw.fit_report_["stats_with_s"] is True
+    else:
+        assert calls["xcov_ssq"] == len(blocks) and calls["xcov_stats"] == 0 and raw.fit_report_["stats_with_s"] is False
     for h, b in zip(held, blocks):
         assert np.array_equal(h.numpy(), b)                                    # the caller's blocks: same bits afterwards
     cen, _ = fit(False)

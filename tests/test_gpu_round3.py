@@ -483,7 +483,7 @@ def test_score_contract_declines_rows_outside_the_registers_of_its_workgroups(be
 @pytest.mark.parametrize("raw", [True, False])
 @pytest.mark.parametrize("dtype,shape", [("float32", (160, 128, 128)), ("float64", (160, 64, 128)), ("float32", (500, 4096)),
                                          ("float32", (300, 8, 16, 32)),
-                                         ("float32", (72, 256, 256)), ("float64", (90, 160, 128))])      # round 4: rows split over workgroups
+                                         ("float32", (72, 160, 256)), ("float64", (90, 160, 128))])      # round 4: rows split over workgroups
 def test_xcov_fit_with_one_read_per_component_equals_the_two_reads(api, monkeypatch, dtype, shape, raw):
     """tPLS(algorithm="xcov") on one block reads X once per component (plus the two reads that build S and the norm): the second
     read is replaced by X_0^T yhat = sum_j b_j r_j with r_j = X_0^T t_j kept from the pass that formed t_j.  Same iterations, same
@@ -684,7 +684,7 @@ def test_xcov_ssq_kernel_gives_s_and_the_centred_norm_from_one_read(be, dtype, I
 def test_xcov_raw_fit_takes_the_norm_from_the_s_build(api, monkeypatch, dtype, shape):
     """A fit on the uncentred tensor needs |X - X_mean|^2 for R2X: from the read that builds S (cmtfpls_xcov_ssq_*) instead of
     a read of its own (cmtfpls_recon_r2_* against a zero reconstruction).  Same R2X."""
-    opt = {}                                              # EngineOptions fields this test overrides
+    opt = {"xcov_stats_with_s": False}                    # (round 4 takes the column statistics out of that read too: tested in test_gpu_round4.py)
     x, y, _ = O.import_synthetic(shape, 5, 4, error=0.1, seed=41)
     x = x + 6.0
     if dtype == "float32":

@@ -466,3 +466,86 @@ def test_rank1_chain_gives_up_loudly_and_the_engine_falls_back_to_launches(api):
             assert _normwise(m.X_factors[0], ref.X_factors[0]) <= 1e-9
     finally:
         lib.cmtfpls_rank1_chain_enable(1)
+
+
+# ---- the column statistics out of the read that builds S (second session of round 4) --------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("I,P,M", [(4096, 16384, 16), (1000, 4096, 32), (777, 1000, 5), (130, 514, 48), (64, 256, 1), (333, 65536, 64)])
+def test_xcov_stats_kernel_gives_s_and_the_column_statistics_from_one_read(dtype, I, P, M):
+    """cmtfpls_xcov_stats_*: S bit for bit the matrix-core pass of cmtfpls_xcov_*, the column sums and sums of squares of tpls.py:61-71
+    from the same read; a missing value shows as a NaN in its column's sum."""
+    from cmtf_pls_amd.backend import HipBackend
+    be = HipBackend("cuda:0")
+    rng = np.random.default_rng(I + P + M)
+    x = rng.normal(size=(I, P)) * rng.uniform(0.5, 2.0, size=P) + rng.normal(size=P) * 5.0
+    if dtype == torch.float32:
+        x = x.astype(np.float32).astype(np.float64)
+    y = rng.normal(size=(I, M))
+    X, Y = torch.from_numpy(x).cuda().to(dtype), torch.from_numpy(y).cuda()
+    S, stats = be.xcov_stats(X, Y, out=be.empty(M, P))
+    assert torch.equal(S, be.xcov(X, Y, False, out=be.empty(M, P)))
+    got = stats.cpu().numpy()
+    assert np.abs(got[:P] - x.sum(axis=0)).max() <= 1e-12 * np.abs(x).sum(axis=0).max()
+    assert np.abs(got[P:] - (x * x).sum(axis=0)).max() <= 1e-12 * (x * x).sum(axis=0).max()
+    X[I // 2, P // 3] = float("nan")
+    _, stats = be.xcov_stats(X, Y, out=be.empty(M, P))
+    bad = torch.isnan(stats[:P]).nonzero().reshape(-1).tolist()
+    assert bad == [P // 3]
+    assert be.xcov_stats(X, torch.zeros(I, 65, dtype=torch.float64, device="cuda:0"), out=be.empty(65, P)) is None
+
+
+@pytest.mark.parametrize("dtype,shape", [("float32", (400, 128, 128)), ("float64", (300, 24, 32)), ("float32", (350, 96)), ("float32", (200, 256, 256))])
+def test_xcov_raw_fit_reads_x_once_before_its_first_component(api, monkeypatch, dtype, shape):
+    """tpls.py:61-71 + the first S from ONE read of the caller's uncentred tensor (backend.xcov_stats): no statistics pass over X, no
+    xcov_ssq; same fit as with the statistics pass first (EngineOptions.xcov_stats_with_s = False) -- the means are summed in another
+    order, so equal to rounding, not bit for bit -- and as the oracle; the tensor is not written."""
+    from cmtf_pls_amd.backend import HipBackend
+    x, y, _ = O.import_synthetic(shape, 5, 4, error=0.1, seed=41)
+    x = x + 6.0
+    if dtype == "float32":
+        x, y = _f32(x), _f32(y)
+    P = int(np.prod(shape[1:]))
+    seen = {"colstats_x": 0, "xcov_stats": 0, "xcov_ssq": 0}
+    for name in ("colstats", "xcov_stats", "xcov_ssq"):
+        orig = getattr(HipBackend, name)
+
+        def counted(self, X2, *a, __orig=orig, __name=name, **k):
+            if __name != "colstats":
+                seen[__name] += 1
+            elif X2.shape[1] == P:
+                seen["colstats_x"] += 1
+            return __orig(self, X2, *a, **k)
+        monkeypatch.setattr(HipBackend, name, counted)
+    X = torch.from_numpy(x).cuda().to(torch.float32 if dtype == "float32" else torch.float64)
+    keep = X.clone()
+    one = api.tPLS(4, dtype=dtype, algorithm="xcov", copy_X=False)
+    one.fit(X, y)
+    assert seen == {"colstats_x": 0, "xcov_stats": 1, "xcov_ssq": 0}, seen
+    assert one.fit_report_["stats_with_s"] is True and one.fit_report_["raw"] and torch.equal(X, keep)
+    two = api.tPLS(4, dtype=dtype, algorithm="xcov", copy_X=False, options=default_options().but(xcov_stats_with_s=False))
+    two.fit(X, y)
+    assert seen == {"colstats_x": 1, "xcov_stats": 1, "xcov_ssq": 1} and two.fit_report_["stats_with_s"] is False
+    assert one.n_iter_ == two.n_iter_
+    for f, g in zip(one.X_factors + one.Y_factors, two.X_factors + two.Y_factors):
+        assert _normwise(f, g) <= 1e-10
+    assert_allclose(one.R2X, two.R2X, rtol=0, atol=1e-11)
+    assert_allclose(one.X_mean, two.X_mean, rtol=0, atol=1e-12 * np.abs(two.X_mean).max())
+    fit = O.fit_tpls(x, y, 4) if shape[0] > 200 or len(shape) == 2 else None
+    if fit is not None:
+        assert one.n_iter_ == fit.n_iter
+        assert_allclose(one.R2X, fit.r2x[0], rtol=0, atol=1e-6 if dtype == "float32" else 1e-9)
+
+
+def test_one_missing_value_the_probe_did_not_see_sends_the_fit_to_the_masked_statistics(api):
+    """The optimistic read finds a NaN in a column sum (the <= 256-row probe had not met it): the regular statistics pass and the
+    masked forms take over, the report says why, the fit equals the one that never tried."""
+    x, y, _ = O.import_synthetic((600, 16, 24), 4, 3, error=0.1, seed=13)
+    x[301, 5, 7] = np.nan                                          # (the probe takes rows 0, 2, 4, ...)
+    m = api.tPLS(3, algorithm="xcov")
+    m.fit(x, y)
+    assert m.X_hasMiss and m.fit_report_["stats_with_s"] is False
+    assert any("non-finite" in d for d in m.fit_report_["declined"]), m.fit_report_["declined"]
+    ref = api.tPLS(3, algorithm="xcov", options=default_options().but(xcov_stats_with_s=False))
+    ref.fit(x, y)
+    assert m.n_iter_ == ref.n_iter_
+    assert np.array_equal(m.X_factors[0], ref.X_factors[0])
