@@ -18,14 +18,14 @@
 //    (v_mfma_f64_16x16x4_f64, operands straight from L2 in the MFMA layout, the 16 wavefronts of the workgroup dealing the
 //    lower-triangular 16 x 16 tiles among themselves), one exact pass with Z, sign rule on the last mode.
 // Arithmetic: float64 throughout, the reference's operation order outside the re-association above.
-// Limits: X of order 2 or 3 without missing values, min(A, B) <= 256, M <= 64, R <= 64, the workgroup's small vectors in
+// Limits: X of order 2 or 3 without missing values, min(A, B) <= 256, M <= 128, R <= 64, the workgroup's small vectors in
 // 150 KB of LDS; per resident fold a workspace of I P + M P + 3 P + 2 n^2 + I (M + R + 2) + R (A + B) doubles (cmtfpls_loo_xcov_fold_workspace_bytes).
 #include "common.hpp"
 
 namespace cmtfpls {
 
 constexpr int kLxNT = 1024, kLxWaves = kLxNT / 64;
-constexpr int kLxMaxN = 256, kLxMaxM = 64, kLxMaxR = 64;
+constexpr int kLxMaxN = 256, kLxMaxM = 128, kLxMaxR = 64;     // (M: as far as the M x M Gram of the responses fits the LDS next to the rest)
 
 typedef double lx_d4_t __attribute__((ext_vector_type(4)));
 
@@ -505,7 +505,7 @@ int cmtfpls_loo_xcov_f64(const double* X, const double* Y, const double* colsum_
   const int n = A < B ? A : B;
   const size_t lds = lx_lds_bytes(A, B, M, R);
   if (n > kLxMaxN || M > kLxMaxM || R > kLxMaxR || lds > 150 * 1024 || (int64_t)A * B > (int64_t)1 << 24) {
-    set_error("loo_xcov: shape outside the workgroup-per-fold form (min(A, B) <= 256, M <= 64, R <= 64); refit per fold on the regular engine");
+    set_error("loo_xcov: shape outside the workgroup-per-fold form (min(A, B) <= 256, M <= 128, R <= 64, small vectors within 150 KB of LDS); refit per fold on the regular engine");
     return CMTFPLS_EUNSUPPORTED;
   }
   const size_t per = cmtfpls_loo_xcov_fold_workspace_bytes(I, A, B, M, R);

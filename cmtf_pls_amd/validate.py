@@ -5,7 +5,7 @@ The reference reads ``pls_tensor.original_X / original_Y``, which its own ``tPLS
 keeps them.  One refit per held-out sample (validate.py:27-33).  On the GPU the folds run side by side, a workgroup per
 fold doing the whole fit for it with the fold's means down-dated from shared column sums: ``cmtfpls_loo_tpls_f64`` when the
 fold's vectors fit the LDS (min(J, K) <= 64), ``cmtfpls_loo_xcov_f64`` beyond (min(J, K) <= 256: the fold's NIPALS loop on its
-cross-covariance, Gram squarings on the matrix cores) -- X of order 2 or 3 without missing values, M <= 64, R <= 16 (LDS form) / 64 (xcov form).  Anything else
+cross-covariance, Gram squarings on the matrix cores) -- X of order 2 or 3 without missing values, M <= 64 / R <= 16 (LDS form), M <= 128 / R <= 64 (xcov form).  Anything else
 refits once per fold on the regular engine with the fitted model's storage type, algorithm and backend.  Which form ran is
 recorded on the model (``q2y_report_``).
 """
@@ -51,7 +51,7 @@ def get_q2y(pls_tensor, device_folds: bool = True):
     Y_actual = Y.astype(float)
     if Y_pred is None:
         why = ("device folds switched off" if not device_folds else
-               "order > 3, missing values, min(J, K) > 256, M > 64 or R > 64: outside both workgroup-per-fold kernels")
+               "order > 3, missing values, min(J, K) > 256, M > 128 (or an M x M Gram beyond the LDS) or R > 64: outside both workgroup-per-fold kernels")
         pls_tensor.q2y_report_ = {"form": "one refit per fold on the regular engine", "folds": int(n), "why": why}
         refit = tPLS(pls_tensor.n_components, dtype=pls_tensor._dtype, device=pls_tensor._device,
                      backend=pls_tensor._backend, algorithm=pls_tensor._algorithm)

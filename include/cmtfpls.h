@@ -457,7 +457,7 @@ int cmtfpls_loo_tpls_f64(const double* X, const double* Y, const double* colsum_
                          int B, int M, int R, double tol, int max_iter, int fold0, int nfolds, double* Ypred,
                          int* n_iter, void* ws, size_t ws_bytes, void* stream);
 /* loo_xcov (round 4): the same leave-one-out refits for trailing shapes BEYOND the LDS-resident form -- min(A, B) <= 256 (128 x 128,
- * 256 x 256), M <= 64, R <= 64 -- one 1024-thread workgroup per fold.  The fold's means are down-dated from the column sums; inside a
+ * 256 x 256), M <= 128 (second session of round 4: 64 before), R <= 64 -- one 1024-thread workgroup per fold.  The fold's means are down-dated from the column sums; inside a
  * component the NIPALS loop runs on the fold's cross-covariance S = Y_f^T X_f (M x P, formed once per component: tpls.py:83 becomes
  * S^T q, tpls.py:100 becomes S w, tpls.py:103 the quadratic form with Y_f^T Y_f), so an inner iteration reads 2 M P doubles
  * instead of the fold's 2 I P; the rank-1 extraction squares the n x n Gram matrix on the f64 matrix cores inside the workgroup.

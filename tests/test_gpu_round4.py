@@ -403,7 +403,8 @@ def test_loo_xcov_kernel_equals_the_lds_kernel_where_both_apply():
 
 
 @pytest.mark.parametrize("shape,M,R", [((48, 80, 96), 3, 3), ((40, 96, 70), 4, 2), ((36, 128, 128), 16, 4), ((20, 256, 256), 32, 2),
-                                       ((44, 72, 80), 3, 20)])      # more than 16 components: the loadings of all components live in the fold's workspace
+                                       ((44, 72, 80), 3, 20),      # more than 16 components: the loadings of all components live in the fold's workspace
+                                       ((36, 40, 30), 96, 2), ((30, 80, 72), 100, 3)])      # more than 64 responses (the LDS form declines, the xcov form takes them)
 def test_q2y_beyond_the_lds_shapes_equals_literal_refits(api, shape, M, R):
     """validate.get_q2y (validate.py:24-37) at trailing shapes with min(J, K) > 64 -- one refit per fold on the regular engine in
     round 3 -- through cmtfpls_loo_xcov_f64: Q2Y and every held-out prediction equal the literal refits' at 1e-8."""
