@@ -675,6 +675,17 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // caller switches the chain off for the rest of the process: cmtfpls_rank1_chain_enable(0).
 static std::atomic<int> g_chain_on{1};
 
+// workgroups of the chain kernel the device can hold at once: two per CU (198 VGPRs, 50 KB of LDS)
+static int chain_slots() {
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots = 2 * cus;
+  }
+  return slots;
+}
+
 }  // namespace cmtfpls
 
 using namespace cmtfpls;
@@ -759,7 +770,7 @@ static int rank1_run(const double* Z, int A, int B, double* wA, double* wB, doub
   const dim3 grid(nt, nt), block(kTile, kTile);
   const int ny_blocks = (k + 31) / 32;
   const double* gave = nullptr;
-  if (allow_chain && g_chain_on.load(std::memory_order_relaxed) && nt * nt <= 256 && n_squarings <= kChainMaxSteps) {
+  if (allow_chain && g_chain_on.load(std::memory_order_relaxed) && nt * nt <= 256 && nt * nt <= chain_slots() && n_squarings <= kChainMaxSteps) {
     // every step in ONE launch (syrk_chain_kernel): G_s | traces | sums of squares of steps 0 .. n_squarings, preset to the
     // pattern that means "not yet written"
     const size_t nn = (size_t)n * n, steps = (size_t)n_squarings + 1;
